@@ -1,0 +1,265 @@
+/*
+ * rnamc.h — C ABI of librnamc.so: the MI355X-native McCaskill partition-function /
+ * base-pairing-probability (bpp) hot path of heartsh/rna-algos.
+ *
+ * This is the drop-in boundary.  The reference has no FFI of its own; the entry
+ * points below are what a Rust `extern "C"` block inside the crate's
+ * `src/mccaskill_algo.rs` would bind so that
+ *
+ *     pub fn mccaskill_algo<T>(seq, uses_contra_model, allows_short_hairpins,
+ *                              fold_score_sets) -> (SparseProbMat<T>, FoldScores<T>)
+ *     (reference: src/mccaskill_algo.rs:247-280)
+ *
+ * keeps its signature while its body becomes "pack -> rnamc_bpp_batch -> unpack"
+ * (binding shown in INTEGRATION.md).  Plain pointers and sizes only; no C++ or
+ * torch types cross this line.  Every function returns an `int` status
+ * (RNAMC_OK == 0) and never aborts or throws; the Rust shim turns a non-zero
+ * status into `panic!()` to preserve the reference's error behaviour
+ * (src/utils.rs:570-572, src/mccaskill_algo.rs:526).
+ *
+ * Scoring tables are INPUTS.  The reference takes its Turner-2004 and
+ * CONTRAfold v2.02 numbers from the third-party crate `rna-ss-params = "0.1"`
+ * (Cargo.toml:12, glob-imported at src/utils.rs:8-10), which is not part of the
+ * reference tree; `rnamc_params` below holds every table the path reads
+ *  with fixed shapes, and is filled from a table file
+ * (rnamc_params_load) or from the seeded synthetic generator
+ * (rnamc_params_synthetic).
+ */
+#ifndef RNAMC_H
+#define RNAMC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RNAMC_ABI_VERSION 2u
+
+/* Compile-time limits.  In the reference these are constants of rna-ss-params
+ * (recalled values): NUM_BASES, MAX_2LOOP_LEN (src/utils.rs:308),
+ * MAX_LOOP_LEN (src/mccaskill_algo.rs:32-34,405), MIN_SPAN_HAIRPIN_CLOSE
+ * (src/mccaskill_algo.rs:290), MAX_INTERIOR_* (src/mccaskill_algo.rs:35-36,43). */
+#define RNAMC_NUM_BASES 4
+#define RNAMC_MAX_2LOOP_LEN 30
+#define RNAMC_MAX_LOOP_LEN 30
+#define RNAMC_MIN_SPAN_HAIRPIN_CLOSE 5
+#define RNAMC_MAX_INTERIOR_EXPLICIT 4
+#define RNAMC_MAX_INTERIOR_SYMMETRIC 15
+#define RNAMC_MAX_INTERIOR_ASYMMETRIC 28
+#define RNAMC_MAX_SPECIAL_HAIRPINS 64
+#define RNAMC_MAX_SPECIAL_HAIRPIN_LEN 16
+/* Longest sequence the reference's callers can pass (T = u16,
+ * src/bin/mccaskill_algo.rs:70-90). */
+#define RNAMC_MAX_SEQ_LEN 65535u
+
+/* Base codes (bytes2seq, src/utils.rs:562-577). */
+#define RNAMC_A 0
+#define RNAMC_C 1
+#define RNAMC_G 2
+#define RNAMC_U 3
+
+/* Status codes. */
+#define RNAMC_OK 0
+#define RNAMC_ERR_INVALID_ARG 1   /* null pointer, bad size, bad ABI version      */
+#define RNAMC_ERR_INVALID_BASE 2  /* byte outside ACGUacgu / code outside 0..3    */
+#define RNAMC_ERR_EMPTY_SEQ 3     /* n == 0 (reference panics: mccaskill_algo.rs:526) */
+#define RNAMC_ERR_SEQ_TOO_LONG 4  /* n > 65535                                     */
+#define RNAMC_ERR_NO_DEVICE 5     /* no HIP device / HIP runtime failure at init   */
+#define RNAMC_ERR_OOM 6           /* host or device allocation failed              */
+#define RNAMC_ERR_HIP 7           /* a HIP call failed (see rnamc_last_error)      */
+#define RNAMC_ERR_IO 8            /* table file could not be read / written        */
+#define RNAMC_ERR_FORMAT 9        /* table file has wrong magic / version / size   */
+
+/* ------------------------------------------------------------------------- */
+/* The CONTRAfold parameter set: field-for-field mirror of `FoldScoreSets`
+ * (reference: src/utils.rs:91-119; constructor/accumulate/transfer at
+ * src/mccaskill_algo.rs:24-211).  All f32 (`Score`). */
+typedef struct rnamc_fold_score_sets {
+  float hairpin_scores_len[RNAMC_MAX_LOOP_LEN + 1];
+  float bulge_scores_len[RNAMC_MAX_LOOP_LEN];
+  float interior_scores_len[RNAMC_MAX_LOOP_LEN - 1];
+  float interior_scores_symmetric[RNAMC_MAX_INTERIOR_SYMMETRIC];
+  float interior_scores_asymmetric[RNAMC_MAX_INTERIOR_ASYMMETRIC];
+  float stack_scores[4][4][4][4];
+  float terminal_mismatch_scores[4][4][4][4];
+  float dangling_scores_left[4][4][4];
+  float dangling_scores_right[4][4][4];
+  float helix_close_scores[4][4];
+  float basepair_scores[4][4];
+  float interior_scores_explicit[RNAMC_MAX_INTERIOR_EXPLICIT][RNAMC_MAX_INTERIOR_EXPLICIT];
+  float bulge_scores_0x1[4];
+  float interior_scores_1x1[4][4];
+  float multibranch_score_base;
+  float multibranch_score_basepair;
+  float multibranch_score_unpair;
+  float external_score_basepair;
+  float external_score_unpair;
+  /* cumulative ("at least") forms, filled by rnamc_fold_score_sets_accumulate */
+  float hairpin_scores_len_cumulative[RNAMC_MAX_LOOP_LEN + 1];
+  float bulge_scores_len_cumulative[RNAMC_MAX_LOOP_LEN];
+  float interior_scores_len_cumulative[RNAMC_MAX_LOOP_LEN - 1];
+  float interior_scores_symmetric_cumulative[RNAMC_MAX_INTERIOR_SYMMETRIC];
+  float interior_scores_asymmetric_cumulative[RNAMC_MAX_INTERIOR_ASYMMETRIC];
+} rnamc_fold_score_sets;
+
+/* The Turner-2004 constants the path reads straight from rna-ss-params
+ * (call sites: src/utils.rs:166-411, src/mccaskill_algo.rs:364,367,594).
+ * Values are scores, i.e. free energies already multiplied by -1/(kT). */
+typedef struct rnamc_turner_scores {
+  float hairpin_scores_init[RNAMC_MAX_LOOP_LEN + 1];           /* HAIRPIN_SCORES_INIT            */
+  float terminal_mismatch_scores_hairpin[4][4][4][4];          /* TERMINAL_MISMATCH_SCORES_HAIRPIN */
+  float stack_scores[4][4][4][4];                              /* STACK_SCORES                   */
+  float bulge_scores_init[RNAMC_MAX_2LOOP_LEN + 1];            /* BULGE_SCORES_INIT              */
+  float interior_scores_init[RNAMC_MAX_2LOOP_LEN + 1];         /* INTERIOR_SCORES_INIT           */
+  float interior_scores_1x1[4][4][4][4][4][4];                 /* INTERIOR_SCORES_1X1            */
+  float interior_scores_1x2[4][4][4][4][4][4][4];              /* INTERIOR_SCORES_1X2            */
+  float interior_scores_2x2[4][4][4][4][4][4][4][4];           /* INTERIOR_SCORES_2X2            */
+  float terminal_mismatch_scores_1xmany[4][4][4][4];
+  float terminal_mismatch_scores_2x3[4][4][4][4];
+  float terminal_mismatch_scores_interior[4][4][4][4];
+  float terminal_mismatch_scores_multibranch[4][4][4][4];
+  float dangling_scores_5prime[4][4][4];
+  float dangling_scores_3prime[4][4][4];
+  float helix_augu_end_penalty;
+  float coeff_hairpin_len_extrapolation;
+  float ninio_coeff;
+  float ninio_max;
+  float init_multibranch_base;
+  float coeff_num_branches;
+  /* HAIRPIN_SCORES_SPECIAL: (whole hairpin incl. closing pair, score), compared by
+   * slice equality (src/utils.rs:198-205).  bases are codes 0..3. */
+  float special_hairpin_scores[RNAMC_MAX_SPECIAL_HAIRPINS];
+  uint8_t special_hairpin_seqs[RNAMC_MAX_SPECIAL_HAIRPINS][RNAMC_MAX_SPECIAL_HAIRPIN_LEN];
+  uint8_t special_hairpin_lens[RNAMC_MAX_SPECIAL_HAIRPINS];
+  uint32_t num_special_hairpins;
+  uint32_t min_hairpin_len;                /* MIN_HAIRPIN_LEN                 (recalled: 3)  */
+  uint32_t max_hairpin_len_extrapolation;  /* MAX_HAIRPIN_LEN_EXTRAPOLATION   (recalled: 9)  */
+  uint32_t min_hairpin_len_extrapolation;  /* MIN_HAIRPIN_LEN_EXTRAPOLATION   (recalled: 10) */
+} rnamc_turner_scores;
+
+typedef struct rnamc_params {
+  uint32_t abi_version;   /* must be RNAMC_ABI_VERSION                     */
+  uint32_t struct_bytes;  /* must be sizeof(rnamc_params)                   */
+  uint64_t table_id;      /* provenance tag: synthetic seed, or file hash   */
+  rnamc_turner_scores turner;
+  rnamc_fold_score_sets contra;
+} rnamc_params;
+
+/* ------------------------------------------------------------------------- */
+/* Misc. */
+uint32_t rnamc_abi_version(void);
+size_t rnamc_params_sizeof(void);
+const char* rnamc_strerror(int status);
+/* Thread-local detail of the last failing call on this thread (HIP error text). */
+const char* rnamc_last_error(void);
+
+/* bytes2seq (src/utils.rs:562-577): ASCII ACGUacgu -> codes 0..3; any other byte
+ * -> RNAMC_ERR_INVALID_BASE (the reference panics). */
+int rnamc_bytes2seq(const uint8_t* ascii, uint64_t n, uint8_t* codes);
+
+/* Number of f32 slots of one sequence's packed bpp triangle: n(n+1)/2. */
+uint64_t rnamc_bpp_len(uint32_t n);
+/* Index of pair (i,j), i <= j < n, in the packed triangle (diagonal-major:
+ * all pairs with j-i = d are contiguous, ordered by i). */
+uint64_t rnamc_bpp_index(uint32_t n, uint32_t i, uint32_t j);
+
+/* ------------------------------------------------------------------------- */
+/* Parameter plumbing. */
+
+/* FoldScoreSets::new(init_val)  (src/mccaskill_algo.rs:25-58). */
+int rnamc_fold_score_sets_new(float init_val, rnamc_fold_score_sets* out);
+/* FoldScoreSets::accumulate     (src/mccaskill_algo.rs:60-86). */
+int rnamc_fold_score_sets_accumulate(rnamc_fold_score_sets* fss);
+/* FoldScoreSets::transfer       (src/mccaskill_algo.rs:88-210): copy the
+ * "compiled" CONTRAfold tables of `src` into `dst`, skipping (leaving as they
+ * are) the entries whose closing pair -- and for stack_scores also the enclosed
+ * pair -- is non-canonical, then accumulate. */
+int rnamc_fold_score_sets_transfer(rnamc_fold_score_sets* dst, const rnamc_fold_score_sets* src);
+
+/* Whole parameter block with every f32 set to init_val (header filled in). */
+int rnamc_params_new(float init_val, rnamc_params* out);
+/* Deterministic synthetic tables for BOTH models (SplitMix64 stream seeded with
+ * `seed`, Turner-like magnitudes; contra tables pass through `transfer`). */
+int rnamc_params_synthetic(uint64_t seed, rnamc_params* out);
+/* Binary table file: 16-byte header {"RNAMCTBL", abi u32, bytes u32} + struct. */
+int rnamc_params_save(const rnamc_params* p, const char* path);
+int rnamc_params_load(const char* path, rnamc_params* out);
+/* Enumerate the f32 array fields of rnamc_params (for host-language mirrors):
+ * returns RNAMC_ERR_INVALID_ARG when idx is past the end. */
+int rnamc_params_field(uint32_t idx, const char** name, uint64_t* byte_offset, uint64_t* count);
+
+/* ------------------------------------------------------------------------- */
+/* Device context: owns the uploaded tables, a workspace and streams on ONE
+ * GPU.  Thread-safe: calls on one ctx are serialised by an internal mutex; use
+ * one ctx per host thread (or per GPU) for concurrency. */
+typedef struct rnamc_ctx rnamc_ctx;
+
+/* device < 0 selects the current HIP device.  workspace_bytes == 0 sizes the DP
+ * workspace lazily from the first batch (grown on demand). */
+int rnamc_ctx_create(const rnamc_params* params, int device, uint64_t workspace_bytes,
+                     rnamc_ctx** out);
+void rnamc_ctx_destroy(rnamc_ctx* ctx);
+/* Tuning knobs (all optional): name in {"group_max_seqs","group_ws_bytes",
+ * "block_threads"}; returns RNAMC_ERR_INVALID_ARG for unknown names. */
+int rnamc_ctx_set(rnamc_ctx* ctx, const char* name, int64_t value);
+
+/* mccaskill_algo over a batch (src/mccaskill_algo.rs:247-280 for each record, as
+ * src/bin/mccaskill_algo.rs:64-93 does on its thread pool).
+ *   bases        concatenated base codes 0..3, host memory
+ *   offsets      n_seqs+1 prefix offsets into `bases`
+ *   bpp          per sequence s the packed triangle of n_s(n_s+1)/2 f32 at
+ *                bpp + out_offsets[s]; entry (i,j) at rnamc_bpp_index; a pair
+ *                absent from the reference's SparseProbMat holds -1.0f
+ *   log_partition  n_seqs f32: sums_external[0][n-1] (may be NULL)
+ * The summation order of every logsumexp fold is the reference's. */
+int rnamc_bpp_batch(rnamc_ctx* ctx, uint32_t n_seqs, const uint8_t* bases,
+                    const uint64_t* offsets, int uses_contra_model, int allows_short_hairpins,
+                    float* bpp, const uint64_t* out_offsets, float* log_partition);
+
+/* Same, with `bases`, `bpp`, `log_partition` already resident in device memory
+ * of ctx's GPU; `offsets`/`out_offsets` stay host arrays.  Work is enqueued on
+ * `hip_stream` (a hipStream_t, may be NULL for the default stream) and the call
+ * returns without synchronising. */
+int rnamc_bpp_batch_device(rnamc_ctx* ctx, uint32_t n_seqs, const uint8_t* d_bases,
+                           const uint64_t* offsets, int uses_contra_model,
+                           int allows_short_hairpins, float* d_bpp, const uint64_t* out_offsets,
+                           float* d_log_partition, void* hip_stream);
+
+/* Per-kernel accounting of the last batch call on this ctx (launch counts and
+ * device time by HIP events on the launch stream; the latter only when
+ * profiling was switched on with rnamc_ctx_set(ctx,"profile",1)). */
+typedef struct rnamc_batch_stats {
+  uint64_t n_groups;
+  uint64_t launches_inside;
+  uint64_t launches_outside;
+  uint64_t launches_other;
+  double ms_inside;   /* sum of event-timed inside sweeps  */
+  double ms_outside;  /* sum of event-timed outside sweeps */
+  double ms_other;
+  uint64_t workspace_bytes;
+} rnamc_batch_stats;
+int rnamc_ctx_last_stats(rnamc_ctx* ctx, rnamc_batch_stats* out);
+
+/* Debug / test hook: copy one DP matrix of sequence `seq_idx` of the LAST group
+ * of the last batch call back to the host as a dense n*n row-major f32 matrix
+ * (cells outside the stored triangle = NaN).  which: 0 sums_close, 1
+ * sums_accessible, 2 sums_external, 3 sums_1ormore_basepairs, 4
+ * multibranch_close_scores, 5 probs_multibranch, 6 probs_multibranch2. */
+int rnamc_debug_fetch(rnamc_ctx* ctx, uint32_t seq_idx, int which, float* out_nxn);
+
+/* ------------------------------------------------------------------------- */
+/* Consumers of the path's output, host side. */
+
+/* centroid_fold (src/centroid_fold.rs:25-105) driven off a packed bpp triangle
+ * as produced above.  pairs_out receives up to max_pairs (i,j) pairs in the
+ * reference's push order; *n_pairs the count; *expect_accuracy the score. */
+int rnamc_centroid_fold(const float* bpp_packed, uint32_t n, float centroid_threshold,
+                        uint32_t* pairs_out, uint32_t max_pairs, uint32_t* n_pairs,
+                        float* expect_accuracy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RNAMC_H */

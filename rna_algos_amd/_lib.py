@@ -1,0 +1,95 @@
+"""ctypes binding of librnamc.so (the C ABI declared in include/rnamc.h).
+
+The HIP extension is the product: if the shared library is missing this module
+raises ImportError("... not built ...") — there is no CPU fallback and nothing
+under oracle/ is ever imported from here.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librnamc.so")
+
+OK = 0
+ERR_INVALID_ARG, ERR_INVALID_BASE, ERR_EMPTY_SEQ, ERR_SEQ_TOO_LONG = 1, 2, 3, 4
+ERR_NO_DEVICE, ERR_OOM, ERR_HIP, ERR_IO, ERR_FORMAT = 5, 6, 7, 8, 9
+
+# every entry point include/rnamc.h declares
+SYMBOLS = [
+    "rnamc_abi_version", "rnamc_params_sizeof", "rnamc_strerror", "rnamc_last_error",
+    "rnamc_bytes2seq", "rnamc_bpp_len", "rnamc_bpp_index",
+    "rnamc_fold_score_sets_new", "rnamc_fold_score_sets_accumulate",
+    "rnamc_fold_score_sets_transfer", "rnamc_params_new", "rnamc_params_synthetic",
+    "rnamc_params_save", "rnamc_params_load", "rnamc_params_field",
+    "rnamc_ctx_create", "rnamc_ctx_destroy", "rnamc_ctx_set",
+    "rnamc_bpp_batch", "rnamc_bpp_batch_device", "rnamc_ctx_last_stats",
+    "rnamc_debug_fetch", "rnamc_centroid_fold",
+]
+
+
+class RnamcError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        msg = lib().rnamc_strerror(status).decode()
+        if detail:
+            msg += ": " + detail
+        super().__init__(f"rnamc status {status}: {msg}")
+
+
+class BatchStats(C.Structure):
+    _fields_ = [
+        ("n_groups", C.c_uint64), ("launches_inside", C.c_uint64),
+        ("launches_outside", C.c_uint64), ("launches_other", C.c_uint64),
+        ("ms_inside", C.c_double), ("ms_outside", C.c_double), ("ms_other", C.c_double),
+        ("workspace_bytes", C.c_uint64),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). rna_algos_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, u8p, u32p, u64p, f32p = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), \
+        C.POINTER(C.c_uint64), C.POINTER(C.c_float)
+    L.rnamc_abi_version.restype = C.c_uint32
+    L.rnamc_params_sizeof.restype = C.c_size_t
+    L.rnamc_strerror.restype = C.c_char_p
+    L.rnamc_strerror.argtypes = [C.c_int]
+    L.rnamc_last_error.restype = C.c_char_p
+    L.rnamc_bytes2seq.argtypes = [vp, C.c_uint64, vp]
+    L.rnamc_bpp_len.restype = C.c_uint64
+    L.rnamc_bpp_len.argtypes = [C.c_uint32]
+    L.rnamc_bpp_index.restype = C.c_uint64
+    L.rnamc_bpp_index.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+    L.rnamc_fold_score_sets_new.argtypes = [C.c_float, vp]
+    L.rnamc_fold_score_sets_accumulate.argtypes = [vp]
+    L.rnamc_fold_score_sets_transfer.argtypes = [vp, vp]
+    L.rnamc_params_new.argtypes = [C.c_float, vp]
+    L.rnamc_params_synthetic.argtypes = [C.c_uint64, vp]
+    L.rnamc_params_save.argtypes = [vp, C.c_char_p]
+    L.rnamc_params_load.argtypes = [C.c_char_p, vp]
+    L.rnamc_params_field.argtypes = [C.c_uint32, C.POINTER(C.c_char_p), u64p, u64p]
+    L.rnamc_ctx_create.argtypes = [vp, C.c_int, C.c_uint64, C.POINTER(vp)]
+    L.rnamc_ctx_destroy.argtypes = [vp]
+    L.rnamc_ctx_destroy.restype = None
+    L.rnamc_ctx_set.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.rnamc_bpp_batch.argtypes = [vp, C.c_uint32, vp, vp, C.c_int, C.c_int, vp, vp, vp]
+    L.rnamc_bpp_batch_device.argtypes = [vp, C.c_uint32, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
+    L.rnamc_ctx_last_stats.argtypes = [vp, C.POINTER(BatchStats)]
+    L.rnamc_debug_fetch.argtypes = [vp, C.c_uint32, C.c_int, vp]
+    L.rnamc_centroid_fold.argtypes = [vp, C.c_uint32, C.c_float, vp, C.c_uint32, u32p, f32p]
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != OK:
+        raise RnamcError(status, lib().rnamc_last_error().decode(errors="replace"))

@@ -1,0 +1,462 @@
+// rnamc_api.cpp — device context and batch orchestration behind the C ABI.
+//
+// A batch of independent sequences (the reference runs one thread-pool task per
+// record: src/bin/mccaskill_algo.rs:64-93) is sorted by length and cut into
+// lock-step groups; each group sweeps the anti-diagonals of all its sequences
+// together, one kernel launch per diagonal and pass, on one HIP stream.  The DP
+// state of a whole group lives in HBM (ten packed triangles per sequence); the
+// 288 GB of an MI355X hold thousands of sequences at once.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "rnamc_device.h"
+
+using namespace rnamc;
+
+#define HIPCHK(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      set_last_error(std::string(#expr) + ": " + hipGetErrorString(_e));                   \
+      return (_e == hipErrorOutOfMemory) ? RNAMC_ERR_OOM : RNAMC_ERR_HIP;                  \
+    }                                                                                      \
+  } while (0)
+
+struct rnamc_ctx {
+  int device = 0;
+  rnamc_params host_params;
+  rnamc_params* d_params = nullptr;
+  float* d_hp_init = nullptr;
+  uint32_t hp_init_len = 0;
+  float* d_ws = nullptr;
+  uint64_t ws_floats = 0;
+  SeqDesc* d_seqs = nullptr;
+  uint64_t seqs_cap = 0;
+  hipStream_t own_stream = nullptr;
+  std::mutex mu;
+  // knobs
+  int64_t group_max_seqs = 512;
+  int64_t group_ws_bytes = 64ll << 30;
+  int64_t block_threads = 256;
+  int64_t profile = 0;
+  // bookkeeping of the last call
+  rnamc_batch_stats stats{};
+  std::vector<SeqDesc> descs;       // all groups, group-major
+  std::vector<uint32_t> group_begin;  // prefix into descs
+  std::vector<hipEvent_t> events;
+};
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess) ok = true;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+uint64_t tri_pad_of(uint32_t n) {
+  uint64_t t = static_cast<uint64_t>(n) * (n + 1ull) / 2ull;
+  return (t + 63ull) & ~63ull;
+}
+
+int ensure_hp_init(rnamc_ctx* c, uint32_t max_n) {
+  if (c->hp_init_len >= max_n + 1 && c->d_hp_init) return RNAMC_OK;
+  const rnamc_turner_scores& t = c->host_params.turner;
+  uint32_t len = std::max<uint32_t>(max_n + 1, 64);
+  std::vector<float> hp(len);
+  const uint32_t m = t.min_hairpin_len_extrapolation - 1;
+  for (uint32_t l = 0; l < len; l++) {
+    if (l <= t.max_hairpin_len_extrapolation) {
+      hp[l] = t.hairpin_scores_init[std::min<uint32_t>(l, RNAMC_MAX_LOOP_LEN)];
+    } else {
+      // HAIRPIN_SCORES_INIT[MIN-1] + COEFF * ln(len / (MIN-1)), all f32 (src/utils.rs:181-183)
+      const float ratio = static_cast<float>(l) / static_cast<float>(m);
+      const float lg = logf(ratio);
+      const float scaled = t.coeff_hairpin_len_extrapolation * lg;
+      hp[l] = t.hairpin_scores_init[m] + scaled;
+    }
+  }
+  if (c->d_hp_init) HIPCHK(hipFree(c->d_hp_init));
+  c->d_hp_init = nullptr;
+  c->hp_init_len = 0;
+  HIPCHK(hipMalloc(&c->d_hp_init, sizeof(float) * len));
+  HIPCHK(hipMemcpy(c->d_hp_init, hp.data(), sizeof(float) * len, hipMemcpyHostToDevice));
+  c->hp_init_len = len;
+  return RNAMC_OK;
+}
+
+int ensure_ws(rnamc_ctx* c, uint64_t floats) {
+  if (c->ws_floats >= floats) return RNAMC_OK;
+  if (c->d_ws) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipFree(c->d_ws));
+    c->d_ws = nullptr;
+    c->ws_floats = 0;
+  }
+  HIPCHK(hipMalloc(&c->d_ws, floats * sizeof(float)));
+  c->ws_floats = floats;
+  return RNAMC_OK;
+}
+
+// Core: everything device-resident, work enqueued on `st`.
+int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint64_t* offsets,
+              bool contra, bool allows_short, float* d_out, const uint64_t* out_offsets,
+              float* d_logz, hipStream_t st) {
+  c->stats = rnamc_batch_stats{};
+  c->descs.clear();
+  c->group_begin.clear();
+  if (n_seqs == 0) return RNAMC_OK;
+  uint32_t max_n = 0;
+  for (uint32_t s = 0; s < n_seqs; s++) {
+    if (offsets[s + 1] < offsets[s]) return RNAMC_ERR_INVALID_ARG;
+    const uint64_t n = offsets[s + 1] - offsets[s];
+    if (n == 0) return RNAMC_ERR_EMPTY_SEQ;
+    if (n > RNAMC_MAX_SEQ_LEN) return RNAMC_ERR_SEQ_TOO_LONG;
+    max_n = std::max<uint32_t>(max_n, static_cast<uint32_t>(n));
+  }
+  int rc = ensure_hp_init(c, max_n);
+  if (rc) return rc;
+
+  // longest first: within a group the sequences active on diagonal d are a prefix
+  std::vector<uint32_t> order(n_seqs);
+  std::iota(order.begin(), order.end(), 0u);
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    return (offsets[a + 1] - offsets[a]) > (offsets[b + 1] - offsets[b]);
+  });
+
+  const uint64_t ws_cap_floats = static_cast<uint64_t>(std::max<int64_t>(c->group_ws_bytes, 1)) / 4;
+  uint64_t max_group_floats = 0;
+  {
+    uint64_t cur = 0;
+    uint32_t cnt = 0;
+    for (uint32_t x = 0; x < n_seqs; x++) {
+      const uint32_t s = order[x];
+      const uint32_t n = static_cast<uint32_t>(offsets[s + 1] - offsets[s]);
+      const uint64_t need = tri_pad_of(n) * M_COUNT;
+      if (cnt > 0 && (cnt >= static_cast<uint32_t>(c->group_max_seqs) || cur + need > ws_cap_floats)) {
+        max_group_floats = std::max(max_group_floats, cur);
+        cur = 0;
+        cnt = 0;
+      }
+      if (cnt == 0) c->group_begin.push_back(static_cast<uint32_t>(c->descs.size()));
+      SeqDesc sd{};
+      sd.n = n;
+      sd.tri_pad = static_cast<uint32_t>(tri_pad_of(n));
+      sd.seq_off = offsets[s];
+      sd.ws_off = cur;
+      sd.out_off = out_offsets[s];
+      sd.batch_idx = s;
+      c->descs.push_back(sd);
+      cur += need;
+      cnt++;
+    }
+    max_group_floats = std::max(max_group_floats, cur);
+    c->group_begin.push_back(static_cast<uint32_t>(c->descs.size()));
+  }
+  rc = ensure_ws(c, max_group_floats);
+  if (rc) return rc;
+  if (c->seqs_cap < c->descs.size()) {
+    if (c->d_seqs) {
+      HIPCHK(hipDeviceSynchronize());
+      HIPCHK(hipFree(c->d_seqs));
+      c->d_seqs = nullptr;
+      c->seqs_cap = 0;
+    }
+    const uint64_t cap = std::max<uint64_t>(c->descs.size(), 1024);
+    HIPCHK(hipMalloc(&c->d_seqs, cap * sizeof(SeqDesc)));
+    c->seqs_cap = cap;
+  }
+  HIPCHK(hipMemcpyAsync(c->d_seqs, c->descs.data(), c->descs.size() * sizeof(SeqDesc),
+                        hipMemcpyHostToDevice, st));
+
+  const size_t n_groups = c->group_begin.size() - 1;
+  const bool prof = c->profile != 0;
+  if (prof) {
+    const size_t need = n_groups * 4;
+    while (c->events.size() < need) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreate(&e));
+      c->events.push_back(e);
+    }
+  }
+  const uint32_t block = static_cast<uint32_t>(c->block_threads);
+  const uint32_t dmin_in = contra ? 0u : (RNAMC_MIN_SPAN_HAIRPIN_CLOSE - 1);
+  const uint32_t dmin_out = (contra && allows_short) ? 1u : (RNAMC_MIN_SPAN_HAIRPIN_CLOSE - 1);
+
+  for (size_t g = 0; g < n_groups; g++) {
+    const uint32_t gb = c->group_begin[g], ge = c->group_begin[g + 1];
+    const uint32_t nseq = ge - gb;
+    const uint32_t gmax = c->descs[gb].n;
+    DeviceBatch b{};
+    b.seqs = c->d_seqs + gb;
+    b.bases = d_bases;
+    b.workspace = c->d_ws;
+    b.out = d_out;
+    b.log_partition = d_logz;
+    b.params = c->d_params;
+    b.hp_init = c->d_hp_init;
+    b.allows_short_hairpins = allows_short ? 1 : 0;
+    // sequences with n > d form a prefix of the group
+    auto active = [&](uint32_t d) {
+      uint32_t lo = 0, hi = nseq;  // first index with n <= d
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (c->descs[gb + mid].n > d) lo = mid + 1; else hi = mid;
+      }
+      return lo;
+    };
+    if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 0], st));
+    launch_init(b, nseq, gmax, st);
+    c->stats.launches_other++;
+    for (uint32_t d = dmin_in; d < gmax; d++) {
+      launch_inside(b, contra, d, gmax - d, active(d), block, st);
+      c->stats.launches_inside += 2;
+    }
+    if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 1], st));
+    for (uint32_t d = gmax; d-- > dmin_out;) {
+      launch_outside(b, contra, d, gmax - d, active(d), block, st);
+      c->stats.launches_outside++;
+    }
+    if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 2], st));
+    launch_finalize(b, nseq, gmax, st);
+    c->stats.launches_other++;
+    if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 3], st));
+    HIPCHK(hipGetLastError());
+  }
+  c->stats.n_groups = n_groups;
+  c->stats.workspace_bytes = c->ws_floats * sizeof(float);
+  if (prof) {
+    HIPCHK(hipStreamSynchronize(st));
+    for (size_t g = 0; g < n_groups; g++) {
+      float a = 0, bms = 0, cc = 0;
+      HIPCHK(hipEventElapsedTime(&a, c->events[4 * g + 0], c->events[4 * g + 1]));
+      HIPCHK(hipEventElapsedTime(&bms, c->events[4 * g + 1], c->events[4 * g + 2]));
+      HIPCHK(hipEventElapsedTime(&cc, c->events[4 * g + 2], c->events[4 * g + 3]));
+      c->stats.ms_inside += a;
+      c->stats.ms_outside += bms;
+      c->stats.ms_other += cc;
+    }
+  }
+  return RNAMC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rnamc_ctx_create(const rnamc_params* params, int device, uint64_t workspace_bytes,
+                     rnamc_ctx** out) {
+  if (!params || !out) return RNAMC_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (params->abi_version != RNAMC_ABI_VERSION || params->struct_bytes != sizeof(rnamc_params)) {
+    set_last_error("rnamc_params header does not match this library's ABI");
+    return RNAMC_ERR_INVALID_ARG;
+  }
+  const rnamc_turner_scores& t = params->turner;
+  if (t.num_special_hairpins > RNAMC_MAX_SPECIAL_HAIRPINS ||
+      t.max_hairpin_len_extrapolation > RNAMC_MAX_LOOP_LEN || t.min_hairpin_len_extrapolation < 2 ||
+      t.min_hairpin_len_extrapolation - 1 > RNAMC_MAX_LOOP_LEN ||
+      t.min_hairpin_len > t.max_hairpin_len_extrapolation) {
+    set_last_error("Turner hairpin limits out of range");
+    return RNAMC_ERR_INVALID_ARG;
+  }
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    set_last_error("no HIP device visible: librnamc has no CPU fallback");
+    return RNAMC_ERR_NO_DEVICE;
+  }
+  if (device < 0) {
+    if (hipGetDevice(&device) != hipSuccess) return RNAMC_ERR_NO_DEVICE;
+  }
+  if (device >= count) return RNAMC_ERR_INVALID_ARG;
+  DeviceGuard guard(device);
+  if (!guard.ok) return RNAMC_ERR_NO_DEVICE;
+  rnamc_ctx* c = new (std::nothrow) rnamc_ctx();
+  if (!c) return RNAMC_ERR_OOM;
+  c->device = device;
+  c->host_params = *params;
+  auto fail = [&](int rc) {
+    rnamc_ctx_destroy(c);
+    return rc;
+  };
+  if (hipMalloc(&c->d_params, sizeof(rnamc_params)) != hipSuccess) return fail(RNAMC_ERR_OOM);
+  if (hipMemcpy(c->d_params, params, sizeof(rnamc_params), hipMemcpyHostToDevice) != hipSuccess)
+    return fail(RNAMC_ERR_HIP);
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess)
+    return fail(RNAMC_ERR_HIP);
+  if (workspace_bytes) {
+    int rc = ensure_ws(c, workspace_bytes / 4);
+    if (rc) return fail(rc);
+  }
+  *out = c;
+  return RNAMC_OK;
+}
+
+void rnamc_ctx_destroy(rnamc_ctx* c) {
+  if (!c) return;
+  {
+    DeviceGuard guard(c->device);
+    (void)hipDeviceSynchronize();
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->d_params) (void)hipFree(c->d_params);
+    if (c->d_hp_init) (void)hipFree(c->d_hp_init);
+    if (c->d_ws) (void)hipFree(c->d_ws);
+    if (c->d_seqs) (void)hipFree(c->d_seqs);
+  }
+  delete c;
+}
+
+int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
+  if (!c || !name) return RNAMC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  const std::string k(name);
+  if (k == "group_max_seqs" && value >= 1) {
+    c->group_max_seqs = std::min<int64_t>(value, 65535);
+  } else if (k == "group_ws_bytes" && value >= 4) {
+    c->group_ws_bytes = value;
+  } else if (k == "block_threads" && value >= 64 && value <= 1024 && value % 64 == 0) {
+    c->block_threads = value;
+  } else if (k == "profile") {
+    c->profile = value;
+  } else {
+    return RNAMC_ERR_INVALID_ARG;
+  }
+  return RNAMC_OK;
+}
+
+int rnamc_bpp_batch_device(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases,
+                           const uint64_t* offsets, int uses_contra_model,
+                           int allows_short_hairpins, float* d_bpp, const uint64_t* out_offsets,
+                           float* d_log_partition, void* hip_stream) {
+  if (!c || !offsets || !out_offsets || (n_seqs && (!d_bases || !d_bpp)))
+    return RNAMC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  DeviceGuard guard(c->device);
+  if (!guard.ok) return RNAMC_ERR_NO_DEVICE;
+  return run_batch(c, n_seqs, d_bases, offsets, uses_contra_model != 0, allows_short_hairpins != 0,
+                   d_bpp, out_offsets, d_log_partition, static_cast<hipStream_t>(hip_stream));
+}
+
+int rnamc_bpp_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* bases, const uint64_t* offsets,
+                    int uses_contra_model, int allows_short_hairpins, float* bpp,
+                    const uint64_t* out_offsets, float* log_partition) {
+  if (!c || !offsets || !out_offsets || (n_seqs && (!bases || !bpp))) return RNAMC_ERR_INVALID_ARG;
+  if (n_seqs == 0) return RNAMC_OK;
+  for (uint32_t s = 0; s < n_seqs; s++) {
+    if (offsets[s + 1] < offsets[s]) return RNAMC_ERR_INVALID_ARG;
+    const uint64_t n = offsets[s + 1] - offsets[s];
+    if (n == 0) return RNAMC_ERR_EMPTY_SEQ;
+    if (n > RNAMC_MAX_SEQ_LEN) return RNAMC_ERR_SEQ_TOO_LONG;
+    for (uint64_t x = offsets[s]; x < offsets[s + 1]; x++)
+      if (bases[x] > 3) return RNAMC_ERR_INVALID_BASE;
+  }
+  std::lock_guard<std::mutex> lock(c->mu);
+  DeviceGuard guard(c->device);
+  if (!guard.ok) return RNAMC_ERR_NO_DEVICE;
+  // device-side packing: bases as given; bpp triangles packed back to back
+  const uint64_t base_lo = offsets[0], base_hi = offsets[n_seqs];
+  std::vector<uint64_t> doff(n_seqs + 1), dout(n_seqs + 1);
+  dout[0] = 0;
+  for (uint32_t s = 0; s < n_seqs; s++) {
+    doff[s] = offsets[s] - base_lo;
+    dout[s + 1] = dout[s] + rnamc_bpp_len(static_cast<uint32_t>(offsets[s + 1] - offsets[s]));
+  }
+  doff[n_seqs] = base_hi - base_lo;
+  uint8_t* d_bases = nullptr;
+  float* d_out = nullptr;
+  float* d_logz = nullptr;
+  int rc = RNAMC_OK;
+  auto cleanup = [&]() {
+    if (d_bases) (void)hipFree(d_bases);
+    if (d_out) (void)hipFree(d_out);
+    if (d_logz) (void)hipFree(d_logz);
+  };
+#define HIPCHK_CLEAN(expr)                                                 \
+  do {                                                                     \
+    hipError_t _e = (expr);                                                \
+    if (_e != hipSuccess) {                                                \
+      set_last_error(std::string(#expr) + ": " + hipGetErrorString(_e));   \
+      cleanup();                                                           \
+      return (_e == hipErrorOutOfMemory) ? RNAMC_ERR_OOM : RNAMC_ERR_HIP;  \
+    }                                                                      \
+  } while (0)
+  HIPCHK_CLEAN(hipMalloc(&d_bases, std::max<uint64_t>(base_hi - base_lo, 1)));
+  HIPCHK_CLEAN(hipMalloc(&d_out, std::max<uint64_t>(dout[n_seqs], 1) * sizeof(float)));
+  HIPCHK_CLEAN(hipMalloc(&d_logz, n_seqs * sizeof(float)));
+  HIPCHK_CLEAN(hipMemcpyAsync(d_bases, bases + base_lo, base_hi - base_lo, hipMemcpyHostToDevice,
+                              c->own_stream));
+  rc = run_batch(c, n_seqs, d_bases, doff.data(), uses_contra_model != 0,
+                 allows_short_hairpins != 0, d_out, dout.data(), d_logz, c->own_stream);
+  if (rc) {
+    (void)hipStreamSynchronize(c->own_stream);
+    cleanup();
+    return rc;
+  }
+  for (uint32_t s = 0; s < n_seqs; s++) {
+    HIPCHK_CLEAN(hipMemcpyAsync(bpp + out_offsets[s], d_out + dout[s],
+                                (dout[s + 1] - dout[s]) * sizeof(float), hipMemcpyDeviceToHost,
+                                c->own_stream));
+  }
+  if (log_partition)
+    HIPCHK_CLEAN(hipMemcpyAsync(log_partition, d_logz, n_seqs * sizeof(float),
+                                hipMemcpyDeviceToHost, c->own_stream));
+  HIPCHK_CLEAN(hipStreamSynchronize(c->own_stream));
+#undef HIPCHK_CLEAN
+  cleanup();
+  return RNAMC_OK;
+}
+
+int rnamc_ctx_last_stats(rnamc_ctx* c, rnamc_batch_stats* out) {
+  if (!c || !out) return RNAMC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  *out = c->stats;
+  return RNAMC_OK;
+}
+
+int rnamc_debug_fetch(rnamc_ctx* c, uint32_t seq_idx, int which, float* out_nxn) {
+  if (!c || !out_nxn) return RNAMC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (c->group_begin.size() < 2) return RNAMC_ERR_INVALID_ARG;
+  const size_t g = c->group_begin.size() - 2;
+  const SeqDesc* sd = nullptr;
+  for (uint32_t x = c->group_begin[g]; x < c->group_begin[g + 1]; x++)
+    if (c->descs[x].batch_idx == seq_idx) sd = &c->descs[x];
+  if (!sd) return RNAMC_ERR_INVALID_ARG;
+  static const int kMat[7] = {M_QB, M_QA, M_Z, M_Q1D, M_MBC, M_PM, M_PM2};
+  if (which < 0 || which > 6) return RNAMC_ERR_INVALID_ARG;
+  const bool row_major = which >= 5;
+  DeviceGuard guard(c->device);
+  if (!guard.ok) return RNAMC_ERR_NO_DEVICE;
+  HIPCHK(hipDeviceSynchronize());
+  const uint32_t n = sd->n;
+  const uint64_t tri = static_cast<uint64_t>(n) * (n + 1ull) / 2ull;
+  std::vector<float> packed(tri);
+  HIPCHK(hipMemcpy(packed.data(), c->d_ws + sd->ws_off + static_cast<uint64_t>(kMat[which]) * sd->tri_pad,
+                   tri * sizeof(float), hipMemcpyDeviceToHost));
+  const float nan = std::numeric_limits<float>::quiet_NaN();
+  for (uint64_t x = 0; x < static_cast<uint64_t>(n) * n; x++) out_nxn[x] = nan;
+  for (uint32_t i = 0; i < n; i++)
+    for (uint32_t j = i; j < n; j++) {
+      const uint64_t d = j - i;
+      const uint64_t idx = row_major ? (static_cast<uint64_t>(i) * n - static_cast<uint64_t>(i) * (i - 1ull) / 2ull + d)
+                                     : (d * n - d * (d - 1ull) / 2ull + i);
+      out_nxn[static_cast<uint64_t>(i) * n + j] = packed[idx];
+    }
+  return RNAMC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,35 @@
+// rnamc_device.h — host<->kernel contract of librnamc.so (internal).
+#ifndef RNAMC_DEVICE_H
+#define RNAMC_DEVICE_H
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+
+#include "rnamc_internal.h"
+
+namespace rnamc {
+
+// One lock-step group of sequences as the kernels see it (passed by value).
+struct DeviceBatch {
+  const SeqDesc* seqs;      // descriptors of this group, longest sequence first
+  const uint8_t* bases;     // base codes of the whole batch
+  float* workspace;         // DP matrices
+  float* out;               // packed bpp triangles of the whole batch
+  float* log_partition;     // may be null
+  const rnamc_params* params;
+  const float* hp_init;     // Turner hairpin initiation by loop length (host-built)
+  int allows_short_hairpins;
+};
+
+void launch_init(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st);
+void launch_inside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t cells, uint32_t nseq,
+                   uint32_t block, hipStream_t st);
+void launch_outside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t cells, uint32_t nseq,
+                    uint32_t block, hipStream_t st);
+void launch_finalize(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st);
+
+}  // namespace rnamc
+
+#endif

@@ -1,0 +1,50 @@
+// rnamc_internal.h — declarations shared by the host and device translation
+// units of librnamc.so.  Not part of the public ABI.
+#ifndef RNAMC_INTERNAL_H
+#define RNAMC_INTERNAL_H
+
+#include <cstdint>
+#include <string>
+
+#include "../../include/rnamc.h"
+
+namespace rnamc {
+
+void set_last_error(const std::string& msg);
+bool is_canonical(int a, int b);
+
+// DP matrices of one sequence inside the workspace.  Every matrix is a packed
+// upper triangle of n(n+1)/2 f32 (padded to a multiple of 64 floats):
+//  - "diag-major": cell (i,j) at  d*n - d(d-1)/2 + i  with d = j-i.  A lane that
+//    owns row i of a diagonal sweep then reads consecutive addresses next to its
+//    neighbours' for every k of the reference's inner loops.
+//  - "row-major":  cell (r,c) at  r*n - r(r-1)/2 + (c-r).
+enum Mat : int {
+  M_QB = 0,   // sums_close                          diag-major
+  M_QA = 1,   // sums_accessible                     diag-major
+  M_MBC = 2,  // multibranch_close_scores            diag-major
+  M_Z = 3,    // sums_external                       diag-major
+  M_Q1D = 4,  // sums_1ormore_basepairs              diag-major
+  M_Q1R = 5,  // sums_1ormore_basepairs              row-major
+  M_ZRE = 6,  // sums_rightmost_basepairs_external   diag-major (inside pass)
+  M_PM = 6,   // probs_multibranch                   row-major  (outside pass, same slot)
+  M_QM = 7,   // sums_multibranch                    diag-major (inside pass)
+  M_PM2 = 7,  // probs_multibranch2                  row-major  (outside pass, same slot)
+  M_W = 8,    // (P + mbclose) - Qb of a pair        diag-major (outside pass)
+  M_ZRM = 9,  // sums_rightmost_basepairs_multibranch diag-major (CONTRAfold only)
+  M_COUNT = 10
+};
+
+struct SeqDesc {
+  uint32_t n;
+  uint32_t tri_pad;   // padded floats per matrix
+  uint64_t seq_off;   // offset of the first base in the bases buffer
+  uint64_t ws_off;    // float offset of this sequence's matrices in the workspace
+  uint64_t out_off;   // float offset of this sequence's bpp triangle in the output
+  uint32_t batch_idx; // position in the caller's batch (for log_partition)
+  uint32_t pad;
+};
+
+}  // namespace rnamc
+
+#endif

@@ -1,0 +1,171 @@
+"""Host-side mirror of the reference's `mccaskill_algo` module over the C ABI.
+
+Reference interface (src/mccaskill_algo.rs:247-255):
+
+    pub fn mccaskill_algo<T>(seq, uses_contra_model, allows_short_hairpins,
+                             fold_score_sets) -> (SparseProbMat<T>, FoldScores<T>)
+
+Same names, argument meaning and error behaviour (an empty sequence or a byte
+outside ACGU raises where the reference panics).  All arithmetic runs in the HIP
+kernels of librnamc.so; nothing here computes.
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _lib
+from .utils import FoldScoreSets, MAX_SEQ_LEN
+
+
+def bpp_len(n):
+    return n * (n + 1) // 2
+
+
+def bpp_index(n, i, j):
+    """Slot of pair (i, j), i <= j, in the packed diagonal-major triangle."""
+    d = j - i
+    return d * n - d * (d - 1) // 2 + i
+
+
+class BppMatrix:
+    """One sequence's result: packed triangle of f32, absent pairs hold -1.0.
+    `sparse()` gives the reference's SparseProbMat<T> as a dict {(i, j): p}."""
+
+    def __init__(self, n, packed):
+        self.n = int(n)
+        self.packed = packed
+
+    def __getitem__(self, ij):
+        i, j = ij
+        return float(self.packed[bpp_index(self.n, i, j)])
+
+    def sparse(self):
+        out = {}
+        n = self.n
+        off = 0
+        for d in range(n):
+            row = self.packed[off:off + n - d]
+            for i in np.nonzero(row >= -0.5)[0]:
+                out[(int(i), int(i) + d)] = float(row[i])
+            off += n - d
+        return out
+
+    def dense(self):
+        n = self.n
+        m = np.full((n, n), -1.0, dtype=np.float32)
+        off = 0
+        for d in range(n):
+            idx = np.arange(n - d)
+            m[idx, idx + d] = self.packed[off:off + n - d]
+            off += n - d
+        return m
+
+
+class FoldScores:
+    """Placeholder of FoldScores<T> (src/mccaskill_algo.rs:13-19): the four score
+    maps are side products no in-crate caller reads; the GPU
+    path recomputes 2-loop scores on the fly and does not materialise them."""
+
+    def __init__(self):
+        self.hairpin_scores = {}
+        self.twoloop_scores = {}
+        self.multibranch_close_scores = {}
+        self.accessible_scores = {}
+
+
+class Context:
+    """Owns one rnamc_ctx (tables + workspace on one GPU)."""
+
+    def __init__(self, fold_score_sets, device=-1, workspace_bytes=0):
+        self._h = C.c_void_p()
+        self._fss = fold_score_sets
+        _lib.check(_lib.lib().rnamc_ctx_create(fold_score_sets.ptr, device, workspace_bytes,
+                                               C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            _lib.lib().rnamc_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def set(self, name, value):
+        _lib.check(_lib.lib().rnamc_ctx_set(self._h, name.encode(), int(value)))
+
+    def stats(self):
+        st = _lib.BatchStats()
+        _lib.check(_lib.lib().rnamc_ctx_last_stats(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
+    def bpp_batch(self, seqs, uses_contra_model, allows_short_hairpins):
+        """seqs: list of np.uint8 code arrays -> (list of BppMatrix, log partition f32[])."""
+        for s in seqs:
+            if len(s) == 0:
+                raise _lib.RnamcError(_lib.ERR_EMPTY_SEQ)
+        lens = np.array([len(s) for s in seqs], dtype=np.uint64)
+        offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        np.cumsum(lens, out=offsets[1:])
+        bases = np.concatenate([np.asarray(s, dtype=np.uint8) for s in seqs]) if seqs else \
+            np.zeros(0, np.uint8)
+        out_offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        np.cumsum(lens * (lens + 1) // 2, out=out_offsets[1:])
+        bpp = np.empty(int(out_offsets[-1]), dtype=np.float32)
+        logz = np.empty(len(seqs), dtype=np.float32)
+        _lib.check(_lib.lib().rnamc_bpp_batch(
+            self._h, len(seqs), bases.ctypes.data, offsets.ctypes.data, int(bool(uses_contra_model)),
+            int(bool(allows_short_hairpins)), bpp.ctypes.data, out_offsets.ctypes.data,
+            logz.ctypes.data))
+        mats = [BppMatrix(int(lens[s]), bpp[int(out_offsets[s]):int(out_offsets[s + 1])])
+                for s in range(len(seqs))]
+        return mats, logz
+
+    def bpp_batch_device(self, n_seqs, d_bases_ptr, offsets, uses_contra_model,
+                         allows_short_hairpins, d_bpp_ptr, out_offsets, d_logz_ptr, stream_ptr):
+        """Everything already in HBM; enqueues on `stream_ptr` and returns."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        out_offsets = np.ascontiguousarray(out_offsets, dtype=np.uint64)
+        _lib.check(_lib.lib().rnamc_bpp_batch_device(
+            self._h, n_seqs, d_bases_ptr, offsets.ctypes.data, int(bool(uses_contra_model)),
+            int(bool(allows_short_hairpins)), d_bpp_ptr, out_offsets.ctypes.data, d_logz_ptr,
+            stream_ptr))
+
+    def debug_fetch(self, seq_idx, which, n):
+        out = np.empty((n, n), dtype=np.float32)
+        _lib.check(_lib.lib().rnamc_debug_fetch(self._h, seq_idx, which, out.ctypes.data))
+        return out
+
+
+_ctx_cache = {}
+_ctx_lock = threading.Lock()
+
+
+def _context_for(fold_score_sets):
+    key = id(fold_score_sets)
+    with _ctx_lock:
+        ctx = _ctx_cache.get(key)
+        if ctx is None or ctx._fss is not fold_score_sets:
+            ctx = Context(fold_score_sets)
+            _ctx_cache[key] = ctx
+        return ctx
+
+
+def mccaskill_algo_packed(seq, uses_contra_model, allows_short_hairpins, fold_score_sets):
+    seq = np.asarray(seq, dtype=np.uint8)
+    if seq.shape[0] > MAX_SEQ_LEN:
+        raise _lib.RnamcError(_lib.ERR_SEQ_TOO_LONG)
+    mats, logz = _context_for(fold_score_sets).bpp_batch([seq], uses_contra_model,
+                                                         allows_short_hairpins)
+    return mats[0], float(logz[0])
+
+
+def mccaskill_algo(seq, uses_contra_model, allows_short_hairpins, fold_score_sets):
+    """(SparseProbMat, FoldScores) like the reference (src/mccaskill_algo.rs:247-280)."""
+    mat, _ = mccaskill_algo_packed(seq, uses_contra_model, allows_short_hairpins, fold_score_sets)
+    return mat.sparse(), FoldScores()
+
+
+def mccaskill_algo_batch(seqs, uses_contra_model, allows_short_hairpins, fold_score_sets):
+    """Whole FASTA at once (what src/bin/mccaskill_algo.rs:64-93 does on a thread pool)."""
+    return _context_for(fold_score_sets).bpp_batch(list(seqs), uses_contra_model,
+                                                   allows_short_hairpins)

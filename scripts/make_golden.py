@@ -1,0 +1,66 @@
+"""Generates tests/golden/*.json|npz from the CPU oracle with the seeded synthetic
+tables ("self-golden, synthetic tables": the reference itself cannot run here and
+holds no golden vectors for this path — SURVEY.md §8c).  Usage:
+    python scripts/make_golden.py [small|n1024|n4096_turner|n4096_contra]
+"""
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O  # noqa: E402
+from rna_algos_amd.utils import FoldScoreSets, read_fasta  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+PARAM_SEED = 1
+
+
+def digest(packed):
+    """sha256 of the f32 bits with the libm-exp branch (p >= 0.9999) canonicalised."""
+    a = np.array(packed, dtype=np.float32, copy=True)
+    a[a >= 0.9999] = 1.0
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+def summary(packed, logz, n, secs):
+    pres = packed >= -0.5
+    return {"n": int(n), "log_partition_bits": int(np.float32(logz).view(np.uint32)),
+            "log_partition": float(logz), "sha256": digest(packed),
+            "present": int(pres.sum()), "max": float(packed.max()),
+            "sum_present": float(packed[pres].astype(np.float64).sum()), "oracle_seconds": secs}
+
+
+def main(which):
+    P = FoldScoreSets.synthetic(PARAM_SEED)
+    if which == "small":
+        recs = read_fasta(os.path.join(GOLD, "sampled_trnas.fa"))
+        arrs = {}
+        for idx, (_, s) in enumerate(recs):
+            for contra in (0, 1):
+                out, lz = O.bpp(P.ptr, s, contra, 0)
+                arrs[f"trna{idx}_{'contra' if contra else 'turner'}"] = out
+                arrs[f"trna{idx}_{'contra' if contra else 'turner'}_logz"] = np.array([lz], np.float32)
+        np.savez_compressed(os.path.join(GOLD, "trna_bpp_synthetic_seed1.npz"), **arrs)
+        return
+    cases = {"n1024": [(1024, 1024, 1), (1024, 1024, 0)], "n4096_turner": [(4096, 4096, 0)],
+             "n4096_contra": [(4096, 4096, 1)]}[which]
+    res = {}
+    for n, seed, contra in cases:
+        s = O.splitmix_seq(n, seed)
+        t0 = time.time()
+        out, lz = O.bpp(P.ptr, s, contra, 0)
+        res[f"n{n}_seed{seed}_{'contra' if contra else 'turner'}"] = summary(out, lz, n, time.time() - t0)
+    path = os.path.join(GOLD, f"checksums_{which}.json")
+    with open(path, "w") as fh:
+        json.dump({"param_seed": PARAM_SEED, "cases": res}, fh, indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "small")
