@@ -145,7 +145,8 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
     for (uint32_t x = 0; x < n_seqs; x++) {
       const uint32_t s = order[x];
       const uint32_t n = static_cast<uint32_t>(offsets[s + 1] - offsets[s]);
-      const uint64_t need = tri_pad_of(n) * M_COUNT;
+      const uint64_t pk_words = ((static_cast<uint64_t>(n) + 160) / 16 + 4 + 63) & ~63ull;
+      const uint64_t need = tri_pad_of(n) * M_COUNT + pk_words;
       if (cnt > 0 && (cnt >= static_cast<uint32_t>(c->group_max_seqs) || cur + need > ws_cap_floats)) {
         max_group_floats = std::max(max_group_floats, cur);
         cur = 0;
@@ -159,6 +160,8 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
       sd.ws_off = cur;
       sd.out_off = out_offsets[s];
       sd.batch_idx = s;
+      sd.pk_words = static_cast<uint32_t>(pk_words);
+      sd.pk_off = cur + tri_pad_of(n) * M_COUNT;
       c->descs.push_back(sd);
       cur += need;
       cnt++;
@@ -221,13 +224,17 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 0], st));
     launch_init(b, nseq, gmax, st);
     c->stats.launches_other++;
+    if (dmin_in > 0 && dmin_in < gmax) {  // closing-pair block of the first diagonal
+      launch_inside(b, contra, dmin_in - 1, gmax, active(dmin_in), block, false, true, st);
+      c->stats.launches_inside++;
+    }
     for (uint32_t d = dmin_in; d < gmax; d++) {
-      launch_inside(b, contra, d, gmax - d, active(d), block, st);
-      c->stats.launches_inside += 2;
+      launch_inside(b, contra, d, gmax, active(d), block, true, d + 1 < gmax, st);
+      c->stats.launches_inside++;
     }
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 1], st));
     for (uint32_t d = gmax; d-- > dmin_out;) {
-      launch_outside(b, contra, d, gmax - d, active(d), block, st);
+      launch_outside(b, contra, d, gmax, active(d), block, st);
       c->stats.launches_outside++;
     }
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 2], st));

@@ -24,9 +24,10 @@ struct DeviceBatch {
 };
 
 void launch_init(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st);
-void launch_inside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t cells, uint32_t nseq,
-                   uint32_t block, hipStream_t st);
-void launch_outside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t cells, uint32_t nseq,
+// folds of diagonal d (do_sums) and closing-pair block of diagonal d+1 (do_pair)
+void launch_inside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
+                   uint32_t block, bool do_sums, bool do_pair, hipStream_t st);
+void launch_outside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
                     uint32_t block, hipStream_t st);
 void launch_finalize(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st);
 

@@ -42,7 +42,8 @@ struct SeqDesc {
   uint64_t ws_off;    // float offset of this sequence's matrices in the workspace
   uint64_t out_off;   // float offset of this sequence's bpp triangle in the output
   uint32_t batch_idx; // position in the caller's batch (for log_partition)
-  uint32_t pad;
+  uint32_t pk_words;  // 32-bit words of the 2-bit packed sequence copy
+  uint64_t pk_off;    // float offset of that copy in the workspace
 };
 
 }  // namespace rnamc

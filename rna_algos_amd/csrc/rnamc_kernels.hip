@@ -16,7 +16,14 @@
 //    the diagonal-major / row-major packed layouts of rnamc_internal.h every
 //    operand of every inner loop is a coalesced 256-B wave access;
 //  * the reduction index k is walked sequentially per lane (order is part of
-//    the result); parallelism comes from cells x sequences, not from k.
+//    the result); parallelism comes from cells x sequences x independent folds,
+//    not from k.  Operands of the next 8 k-steps are fetched into registers
+//    while the current 8 are folded (the loads do not depend on the chain);
+//  * the 8-piece cubic of logsumexp is evaluated branch-free: a 3-compare binary
+//    search gives the piece, one ds_read_b128 fetches its 4 coefficients from LDS;
+//  * each launch carries two independent roles in disjoint blocks: inside =
+//    {folds of diagonal d, closing-pair block of diagonal d+1}, outside =
+//    {probs_multibranch folds, pair probabilities} of diagonal d.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -29,45 +36,64 @@ namespace rnamc {
 namespace {
 
 constexpr float kNegInf = -__builtin_inff();
+constexpr int kU = 8;  // k-steps fetched ahead per lane
 
 // ----------------------------------------------------------------------------
 // numerics: src/utils.rs:579-655
 
-__device__ __forceinline__ float ln_exp_1p(float x) {
-  if (x < 3.3792500f) {
-    if (x < 1.6320158f) {
-      if (x < 0.66153675f) {
-        return ((-0.0065591595f * x + 0.12764427f) * x + 0.49965546f) * x + 0.6931542f;
-      } else {
-        return ((-0.015515756f * x + 0.14467756f) * x + 0.48829398f) * x + 0.6958093f;
-      }
-    } else if (x < 2.4912589f) {
-      return ((-0.012890925f * x + 0.13010283f) * x + 0.51503986f) * x + 0.6795586f;
-    } else {
-      return ((-0.0072142647f * x + 0.087754086f) * x + 0.6208708f) * x + 0.5909676f;
-    }
-  } else if (x < 5.789071f) {
-    if (x < 4.426169f) {
-      return ((-0.0031455354f * x + 0.046722945f) * x + 0.7592532f) * x + 0.43487945f;
-    } else {
-      return ((-0.0010110698f * x + 0.018594341f) * x + 0.88317305f) * x + 0.25236955f;
-    }
-  } else if (x < 7.8162727f) {
-    return ((-0.000196278f * x + 0.0046084408f) * x + 0.9634432f) * x + 0.09831489f;
-  } else {
-    return ((-0.0000113994f * x + 0.0003734731f) * x + 0.9959107f) * x + 0.0149855051f;
+// coefficient rows of ln_exp_1p (src/utils.rs:602-627), piece 0..7 by ascending x
+__constant__ float kLseCoef[8][4] = {
+    {-0.0065591595f, 0.12764427f, 0.49965546f, 0.6931542f},
+    {-0.015515756f, 0.14467756f, 0.48829398f, 0.6958093f},
+    {-0.012890925f, 0.13010283f, 0.51503986f, 0.6795586f},
+    {-0.0072142647f, 0.087754086f, 0.6208708f, 0.5909676f},
+    {-0.0031455354f, 0.046722945f, 0.7592532f, 0.43487945f},
+    {-0.0010110698f, 0.018594341f, 0.88317305f, 0.25236955f},
+    {-0.000196278f, 0.0046084408f, 0.9634432f, 0.09831489f},
+    {-0.0000113994f, 0.0003734731f, 0.9959107f, 0.0149855051f},
+};
+
+__device__ __forceinline__ void load_lse_table(float4* tab) {
+  if (threadIdx.x < 8) {
+    tab[threadIdx.x] = make_float4(kLseCoef[threadIdx.x][0], kLseCoef[threadIdx.x][1],
+                                   kLseCoef[threadIdx.x][2], kLseCoef[threadIdx.x][3]);
   }
+  __syncthreads();
+}
+
+// v_max_f32 / v_min_f32 without the sNaN-quieting canonicalisation hipcc adds in
+// front of fmaxf/fminf (operands here are finite or -inf, never NaN).
+__device__ __forceinline__ float vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmin(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 
 // One fold step sum ⊕ x.  Operands are finite or -inf (never NaN/+inf: absent
 // map entries are -inf and are masked at the source), so the reference's two
 // is_finite() early-outs collapse to "if the smaller one is -inf take the
-// larger one".
-__device__ __forceinline__ float lse(float sum, float x) {
-  float hi = fmaxf(sum, x);
-  float lo = fminf(sum, x);
-  float z = hi - lo;
-  float r = lo + (z >= 11.862479f ? z : ln_exp_1p(z));
+// larger one".  Piece boundaries: `x < t` in the reference <=> !(z >= t).
+__device__ __forceinline__ float lse(float sum, float x, const float4* tab) {
+  const float hi = vmax(sum, x);
+  const float lo = vmin(sum, x);
+  const float z = hi - lo;
+  const bool c1 = z >= 3.3792500f;
+  const float tmid = c1 ? 5.789071f : 1.6320158f;
+  const float tlo = c1 ? 4.426169f : 0.66153675f;
+  const float thi = c1 ? 7.8162727f : 2.4912589f;
+  const bool c2 = z >= tmid;
+  const float t3 = c2 ? thi : tlo;
+  const bool c3 = z >= t3;
+  const unsigned boff = (c1 ? 64u : 0u) | (c2 ? 32u : 0u) | (c3 ? 16u : 0u);
+  const float4 co = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tab) + boff);
+  float r = ((co.x * z + co.y) * z + co.z) * z + co.w;
+  r = (z >= 11.862479f) ? z : r;
+  r = lo + r;
   return (lo == kNegInf) ? hi : r;
 }
 
@@ -101,6 +127,12 @@ __device__ __forceinline__ float expf_ref(float x) {
 // ----------------------------------------------------------------------------
 // index algebra
 
+// load ubase[i] as global_load_dword v, v_off, s[base] (uniform 64-bit base in
+// SGPRs + the lane's 32-bit byte offset) instead of a 64-bit VALU address per load
+__device__ __forceinline__ float ldu(const float* __restrict__ ubase, uint32_t lane_byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ubase) + lane_byte_off);
+}
+
 __device__ __forceinline__ uint32_t tri_off(uint32_t n, uint32_t d) {
   // start of diagonal d (diag-major) == start of row d (row-major)
   return d * n - (d * (d - 1u)) / 2u;
@@ -120,7 +152,8 @@ struct Seq {
   const uint8_t* s;  // base codes
   uint32_t n;
   float* m[M_COUNT];
-  float* out;  // packed bpp triangle (log domain until finalize)
+  float* out;          // packed bpp triangle (log domain until finalize)
+  const uint32_t* pk;  // 2-bit packed bases, 16 per word, position p at bit 2(p+32)
 };
 
 __device__ __forceinline__ Seq load_seq(const DeviceBatch& b, uint32_t which) {
@@ -132,8 +165,49 @@ __device__ __forceinline__ Seq load_seq(const DeviceBatch& b, uint32_t which) {
 #pragma unroll
   for (int x = 0; x < M_COUNT; x++) q.m[x] = base + static_cast<size_t>(x) * sd.tri_pad;
   q.out = b.out + sd.out_off;
+  q.pk = reinterpret_cast<const uint32_t*>(b.workspace + sd.pk_off);
   return q;
 }
+
+// 32 consecutive bases in two registers: window position q holds base p0+q.
+struct Win {
+  uint32_t lo, hi;
+};
+
+// p0 may be as low as -32 (the packed copy carries 32 zero bases in front and
+// >= 64 behind, written by k_init).
+__device__ __forceinline__ Win load_win(const uint32_t* __restrict__ pk, int p0) {
+  const uint32_t bit = 2u * static_cast<uint32_t>(p0 + 32);
+  const uint32_t w = bit >> 5, sh = bit & 31u;
+  const uint32_t w0 = pk[w], w1 = pk[w + 1], w2 = pk[w + 2];
+  Win r;
+  r.lo = __builtin_amdgcn_alignbit(w1, w0, sh);
+  r.hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+  return r;
+}
+
+// base at window position q; q is wave-uniform at every call site
+__device__ __forceinline__ int wbase(const Win& w, uint32_t q) {
+  const uint32_t h = (q < 16u) ? w.lo : w.hi;
+  return static_cast<int>((h >> (2u * (q & 15u))) & 3u);
+}
+
+__device__ __forceinline__ int idx4(int a, int b, int c, int d) { return ((a * 4 + b) * 4 + c) * 4 + d; }
+
+// base codes around one 2-loop: "close" = the closing pair (c0,c1) with its inner
+// neighbours x1 = s[c0+1], y1 = s[c1-1], x2 = s[c0+2], y2 = s[c1-2]; "inner" = the
+// enclosed pair (a0,a1) with its outer neighbours o0 = s[a0-1], o1 = s[a1+1].
+struct TwoLoopCodes {
+  int c0, c1, x1, y1, x2, y2;  // closing side
+  int a0, a1, o0, o1;          // enclosed side
+};
+
+constexpr int kPU = 8;                                   // probes fetched ahead
+constexpr uint32_t kProbes = (RNAMC_MAX_2LOOP_LEN + 1) * (RNAMC_MAX_2LOOP_LEN + 2) / 2;  // 496
+static_assert(kProbes % kPU == 0, "probe list is walked in whole chunks");
+static_assert(RNAMC_MAX_2LOOP_LEN == RNAMC_MAX_LOOP_LEN, "one probe triangle for both models");
+
+#include "rnamc_probes.h"
 
 // ----------------------------------------------------------------------------
 // Turner model scores: src/utils.rs:166-411
@@ -332,46 +406,47 @@ __global__ void k_init(DeviceBatch b) {
   const size_t olen = static_cast<size_t>(sd.n) * (sd.n + 1u) / 2u;
   for (size_t x = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; x < olen; x += stride)
     out[x] = kNegInf;
+  // 2-bit packed copy of the sequence: base p at bit 2(p+32); zeros around it
+  uint32_t* pk = reinterpret_cast<uint32_t*>(b.workspace + sd.pk_off);
+  const uint8_t* s = b.bases + sd.seq_off;
+  for (size_t wd = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; wd < sd.pk_words;
+       wd += stride) {
+    uint32_t v = 0;
+    for (uint32_t y = 0; y < 16; y++) {
+      const int64_t pos = static_cast<int64_t>(wd) * 16 + y - 32;
+      if (pos >= 0 && pos < static_cast<int64_t>(sd.n)) v |= static_cast<uint32_t>(s[pos] & 3u) << (2u * y);
+    }
+    pk[wd] = v;
+  }
 }
 
 // ----------------------------------------------------------------------------
-// inside pass, closing-pair block of diagonal d
+// inside pass, closing-pair block of one cell of diagonal d
 // (src/mccaskill_algo.rs:297-343 Turner, 400-467 CONTRAfold)
 template <bool CONTRA>
-__global__ void k_inside_pair(DeviceBatch b, uint32_t d) {
-  const Seq q = load_seq(b, blockIdx.y);
+__device__ __forceinline__ void inside_pair_cell(const DeviceBatch& b, const Seq& q, uint32_t d,
+                                                 uint32_t i, bool valid, const float4* tab,
+                                                 const ProbeTabs& L) {
   const uint32_t n = q.n;
-  if (d >= n) return;
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n - d) return;
   const uint32_t j = i + d;
   const uint8_t* s = q.s;
-  if (!canonical(s[i], s[j])) return;
-  if (!(b.allows_short_hairpins && CONTRA) && d + 1 < RNAMC_MIN_SPAN_HAIRPIN_CLOSE) return;
+  bool act = valid && canonical(s[i], s[j]);
+  if (!(b.allows_short_hairpins && CONTRA) && d + 1 < RNAMC_MIN_SPAN_HAIRPIN_CLOSE) act = false;
+  if (__ballot(act) == 0ull) return;
   const auto model = ModelOf<CONTRA>::make(b);
 
   float sum = kNegInf;
-  if (!CONTRA || d - 1 <= RNAMC_MAX_LOOP_LEN) sum = lse(sum, model.hairpin(s, n, i, j));
-  // enclosed pairs (k,l) = (i+1+a, j-1-b), a ascending, b ascending (l descending),
-  // a+b <= 30, k < j-1, l > k   <=>   a + b <= d-3   (uniform over the diagonal)
+  if (act && (!CONTRA || d - 1 <= RNAMC_MAX_LOOP_LEN)) sum = lse(sum, model.hairpin(s, n, i, j), tab);
+  // enclosed pairs (k,l) = (i+1+a, j-1-bb), a ascending, bb ascending (l descending),
+  // a+bb <= 30, k < j-1, l > k   <=>   a + bb <= d-3   (uniform over the diagonal)
   if (d >= 3) {
     const uint32_t lim = min(static_cast<uint32_t>(RNAMC_MAX_2LOOP_LEN), d - 3);
-    const float* qb = q.m[M_QB];
-    for (uint32_t a = 0; a <= lim; a++) {
-      const uint32_t k = i + 1 + a;
-      for (uint32_t bb = 0; bb <= lim - a; bb++) {
-        const uint32_t l = j - 1 - bb;
-        const float x = qb[tri_off(n, l - k) + k];
-        if (x > kNegInf) {
-          const float y = model.twoloop(s, i, j, k, l, a, bb);
-          sum = lse(sum, x + y);
-        }
-      }
-    }
+    sum = probe_fold<CONTRA, false>(b, q, d, i, act, lim, sum, 0.f, tab, L);
   }
+  if (!act) return;
   const float mbc = model.mbclose(s, n, i, j);
   const float qm = (d >= 2) ? q.m[M_QM][tri_off(n, d - 2) + i + 1] : kNegInf;
-  sum = lse(sum, qm + mbc);
+  sum = lse(sum, qm + mbc, tab);
   const float acc = model.accessible(s, n, i, j);
   if (sum > kNegInf) {
     const uint32_t o = tri_off(n, d) + i;
@@ -382,191 +457,348 @@ __global__ void k_inside_pair(DeviceBatch b, uint32_t d) {
 }
 
 // ----------------------------------------------------------------------------
-// inside pass, the three Theta(n) folds of diagonal d
+// inside pass, the Theta(n) folds of one cell of diagonal d
 // (src/mccaskill_algo.rs:344-374 Turner, 468-512 CONTRAfold)
 template <bool CONTRA>
-__global__ void k_inside_sums(DeviceBatch b, uint32_t d) {
-  const Seq q = load_seq(b, blockIdx.y);
+__device__ __forceinline__ void inside_sums_cell(const DeviceBatch& b, const Seq& q, uint32_t d,
+                                                 uint32_t i, const float4* tab) {
   const uint32_t n = q.n;
-  if (d >= n) return;
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n - d) return;
   const uint32_t od = tri_off(n, d) + i;  // this cell, diag-major
-  const float* zre = q.m[M_ZRE];
-  const float* zrm = q.m[CONTRA ? M_ZRM : M_ZRE];
-  const float* z = q.m[M_Z];
-  const float* q1 = q.m[M_Q1D];
+  const float* __restrict__ zre = q.m[M_ZRE];
+  const float* __restrict__ zrm = q.m[CONTRA ? M_ZRM : M_ZRE];
+  const float* __restrict__ z = q.m[M_Z];
+  const float* __restrict__ q1 = q.m[M_Q1D];
 
   float zr_ext, zr_mb;
+  float c = 0.f, mun = 0.f;
   if (!CONTRA) {
     // sums_rightmost_basepairs_external(i,j) = fold_{k=i+1..j} sums_accessible(i,k); the
     // terms do not depend on j, so the fold of (i,j-1) extended by one step is the
     // same sequence of operations (344-351).
     const float prev = (d >= 1) ? zre[tri_off(n, d - 1) + i] : kNegInf;
-    zr_ext = lse(prev, q.m[M_QA][od]);
+    zr_ext = lse(prev, q.m[M_QA][od], tab);
     zr_mb = zr_ext;
     q.m[M_ZRE][od] = zr_ext;
+    c = b.params->turner.coeff_num_branches;
   } else {
     const rnamc_fold_score_sets& f = b.params->contra;
     const float ebp = f.external_score_basepair, eun = f.external_score_unpair;
-    const float mbp = f.multibranch_score_basepair, mun = f.multibranch_score_unpair;
-    const float* qa = q.m[M_QA];
+    const float mbp = f.multibranch_score_basepair;
+    mun = f.multibranch_score_unpair;
+    const float* __restrict__ qa = q.m[M_QA];
     zr_ext = kNegInf;
     zr_mb = kNegInf;
-    for (uint32_t t = 1; t <= d; t++) {  // k = i + t, j - k = d - t
-      const float x = qa[tri_off(n, t) + i];
-      if (x > kNegInf) {
-        const float cnt = static_cast<float>(d - t);
-        zr_ext = lse(zr_ext, x + ebp + eun * cnt);
-        zr_mb = lse(zr_mb, x + mbp + mun * cnt);
+    // k = i + t, j - k = d - t; sums_accessible(i,k) is -inf when (i,k) is no pair
+    uint32_t t = 1;
+    for (; t + kU <= d + 1; t += kU) {
+      float xs[kU];
+#pragma unroll
+      for (int u = 0; u < kU; u++) xs[u] = ldu(qa + tri_off(n, t + u), i * 4u);
+#pragma unroll
+      for (int u = 0; u < kU; u++) {
+        const float cnt = static_cast<float>(d - t - u);
+        zr_ext = lse(zr_ext, xs[u] + ebp + eun * cnt, tab);
+        zr_mb = lse(zr_mb, xs[u] + mbp + mun * cnt, tab);
       }
+    }
+    for (; t <= d; t++) {
+      const float x = qa[tri_off(n, t) + i];
+      const float cnt = static_cast<float>(d - t);
+      zr_ext = lse(zr_ext, x + ebp + eun * cnt, tab);
+      zr_mb = lse(zr_mb, x + mbp + mun * cnt, tab);
     }
     q.m[M_ZRE][od] = zr_ext;
     q.m[M_ZRM][od] = zr_mb;
   }
 
   // sums_external (352-363 / 487-498) and sums_1ormore / sums_multibranch
-  // (364-374 / 499-512) share the operand Zr[k][j]; walk k = i + t once.
+  // (364-374 / 499-512) share the walk k = i + t:
+  //   Zr[k][j]   -> diagonal d-t, offset i+t      Z/Q1[i][k-1] -> diagonal t-1, offset i
   float ext, s1, s2 = kNegInf;
   if (!CONTRA) {
-    const float c = b.params->turner.coeff_num_branches;
-    ext = lse(0.f, zr_ext + 0.f);  // k = i: Z[i][i-1] is the lower-triangle 0
+    ext = lse(0.f, zr_ext + 0.f, tab);  // k = i: Z[i][i-1] is the lower-triangle 0
     s1 = zr_ext + c;
-    for (uint32_t t = 1; t < d; t++) {
-      const float r = zre[tri_off(n, d - t) + i + t];
-      const uint32_t o = tri_off(n, t - 1) + i;
-      ext = lse(ext, r + z[o]);
-      const float x = r + c;
-      s1 = lse(s1, x);
-      s2 = lse(s2, q1[o] + x);
-    }
   } else {
-    const rnamc_fold_score_sets& f = b.params->contra;
-    const float mun = f.multibranch_score_unpair;
-    ext = lse(f.external_score_unpair * static_cast<float>(d + 1), zr_ext + 0.f);
+    ext = lse(b.params->contra.external_score_unpair * static_cast<float>(d + 1), zr_ext + 0.f, tab);
     s1 = zr_mb;
-    for (uint32_t t = 1; t < d; t++) {
-      const uint32_t or_ = tri_off(n, d - t) + i + t;
-      const uint32_t o = tri_off(n, t - 1) + i;
-      ext = lse(ext, zre[or_] + z[o]);
-      const float x = zrm[or_];
-      s1 = lse(s1, x + mun * static_cast<float>(t));
-      s2 = lse(s2, q1[o] + x);
+  }
+  auto step = [&](float re, float rm, float zz, float qq, uint32_t t) {
+    ext = lse(ext, re + zz, tab);
+    if (!CONTRA) {
+      const float x = re + c;
+      s1 = lse(s1, x, tab);
+      s2 = lse(s2, qq + x, tab);
+    } else {
+      s1 = lse(s1, rm + mun * static_cast<float>(t), tab);
+      s2 = lse(s2, qq + rm, tab);
+    }
+  };
+  uint32_t t = 1;
+  const uint32_t i4 = i * 4u;
+  if (d > kU) {
+    float re[kU], rm[kU], zz[kU], qq[kU];
+    auto fetch = [&](uint32_t t0) {
+#pragma unroll
+      for (int u = 0; u < kU; u++) {
+        const uint32_t orr = tri_off(n, d - t0 - u) + t0 + u;
+        const uint32_t o = tri_off(n, t0 + u - 1);
+        re[u] = ldu(zre + orr, i4);
+        if (CONTRA) rm[u] = ldu(zrm + orr, i4);
+        zz[u] = ldu(z + o, i4);
+        qq[u] = ldu(q1 + o, i4);
+      }
+    };
+    fetch(t);
+    while (t + kU <= d) {  // steps t .. t+kU-1 are all < d
+      float re2[kU], rm2[kU], zz2[kU], qq2[kU];
+#pragma unroll
+      for (int u = 0; u < kU; u++) {
+        re2[u] = re[u];
+        rm2[u] = CONTRA ? rm[u] : 0.f;
+        zz2[u] = zz[u];
+        qq2[u] = qq[u];
+      }
+      const uint32_t tn = t + kU;
+      if (tn + kU <= d) fetch(tn);  // uniform
+#pragma unroll
+      for (int u = 0; u < kU; u++) step(re2[u], rm2[u], zz2[u], qq2[u], t + u);
+      t = tn;
     }
   }
-  if (d == 0) ext = CONTRA ? b.params->contra.external_score_unpair * 1.f : 0.f;
+  for (; t < d; t++) {
+    const uint32_t orr = tri_off(n, d - t) + t + i;
+    const uint32_t o = tri_off(n, t - 1) + i;
+    step(zre[orr], CONTRA ? zrm[orr] : 0.f, z[o], q1[o], t);
+  }
   q.m[M_Z][od] = ext;
   q.m[M_QM][od] = s2;
-  s1 = lse(s1, s2);
+  s1 = lse(s1, s2, tab);
   q.m[M_Q1D][od] = s1;
   q.m[M_Q1R][tri_off(n, i) + d] = s1;
 }
 
-// ----------------------------------------------------------------------------
-// outside pass of diagonal d (src/mccaskill_algo.rs:537-605 Turner, 638-718
-// CONTRAfold).  basepair_probs stays in the log domain in `out` until k_finalize.
+// One launch of the inside sweep: blocks [0, blocks_sums) fold diagonal d, the
+// remaining blocks evaluate the closing-pair block of diagonal d+1, which needs
+// nothing newer than diagonal d-1 (sums_multibranch[i+1][j-1], sums_close of
+// spans <= d-1) and so runs beside the folds.
 template <bool CONTRA>
-__global__ void k_outside(DeviceBatch b, uint32_t d) {
+__global__ void __launch_bounds__(256) k_inside(DeviceBatch b, uint32_t d, uint32_t blocks_sums,
+                                                int do_sums, int do_pair) {
+  __shared__ float4 tab[8];
+  __shared__ ProbeTabs L;
+  load_lse_table(tab);
+  const Seq q = load_seq(b, blockIdx.y);
+  const uint32_t n = q.n;
+  if (blockIdx.x < blocks_sums) {
+    if (!do_sums || d >= n) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - d) return;
+    inside_sums_cell<CONTRA>(b, q, d, i, tab);
+  } else {
+    const uint32_t dp = d + 1;
+    if (!do_pair || dp >= n) return;  // uniform over the block
+    const uint32_t i = (blockIdx.x - blocks_sums) * blockDim.x + threadIdx.x;
+    const uint32_t wave_first = i - (threadIdx.x & 63u);
+    if (blockIdx.x - blocks_sums > (n - dp - 1) / blockDim.x) return;  // block past the diagonal
+    load_probe_tabs<CONTRA, false>(L, b.params);
+    if (wave_first >= n - dp) return;
+    inside_pair_cell<CONTRA>(b, q, dp, i, i < n - dp, tab, L);
+  }
+}
+
+// ----------------------------------------------------------------------------
+// outside pass (src/mccaskill_algo.rs:537-605 Turner, 638-718 CONTRAfold).
+// basepair_probs stays in the log domain in `out` until k_finalize.
+
+// probs_multibranch / probs_multibranch2 of one cell: k = j + t over pairs (i,k)
+template <bool CONTRA>
+__device__ __forceinline__ void outside_mb_cell(const DeviceBatch& b, const Seq& q, uint32_t d,
+                                                uint32_t i, bool valid, uint32_t cnt_wave,
+                                                const float4* tab) {
+  const uint32_t n = q.n;
+  const uint32_t j = i + d;
+  const float* __restrict__ q1d = q.m[M_Q1D];
+  const float* __restrict__ w = q.m[M_W];
+  const float mun = CONTRA ? b.params->contra.multibranch_score_unpair : 0.f;
+  const uint32_t cnt = valid ? n - 1 - j : 0u;  // this lane's trip count
+  float pm = kNegInf, pm2 = kNegInf;
+  auto step = [&](float x, float r, uint32_t t) {
+    pm = lse(pm, x + r, tab);
+    if (CONTRA) {
+      pm2 = lse(pm2, x + mun * static_cast<float>(t - 1), tab);
+    } else {
+      pm2 = lse(pm2, x, tab);
+    }
+  };
+  // W(i,k): diagonal d+t, offset i (-inf when (i,k) is no pair);
+  // sums_1ormore_basepairs[j+1][k-1]: diagonal t-2, offset j+1 (t == 1: empty interval)
+  const uint32_t i4 = i * 4u;
+  auto ld_w = [&](uint32_t t) { return (t <= cnt) ? ldu(w + tri_off(n, d + t), i4) : kNegInf; };
+  auto ld_r = [&](uint32_t t) {
+    return (t >= 2 && t <= cnt) ? ldu(q1d + tri_off(n, t - 2) + d + 1, i4) : kNegInf;
+  };
+  uint32_t t = 1;
+  if (cnt_wave >= kU) {
+    float xs[kU], rs[kU];
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      xs[u] = ld_w(t + u);
+      rs[u] = ld_r(t + u);
+    }
+    while (t + kU <= cnt_wave + 1) {
+      float xs2[kU], rs2[kU];
+#pragma unroll
+      for (int u = 0; u < kU; u++) {
+        xs2[u] = xs[u];
+        rs2[u] = rs[u];
+      }
+      const uint32_t tn = t + kU;
+      if (tn + kU <= cnt_wave + 1) {
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+          xs[u] = ld_w(tn + u);
+          rs[u] = ld_r(tn + u);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kU; u++) step(xs2[u], rs2[u], t + u);
+      t = tn;
+    }
+  }
+  for (; t <= cnt_wave; t++) step(ld_w(t), ld_r(t), t);
+  if (valid) {
+    const uint32_t orow = tri_off(n, i) + d;
+    q.m[M_PM][orow] = pm;
+    q.m[M_PM2][orow] = pm2;
+  }
+}
+
+// pair probability of one cell: exterior term ⊕ enclosing 2-loops ⊕ multibranch
+// contexts (559-605 / 663-718)
+template <bool CONTRA>
+__device__ __forceinline__ void outside_pair_cell(const DeviceBatch& b, const Seq& q, uint32_t d,
+                                                  uint32_t i, bool valid, uint32_t imax_wave,
+                                                  const float4* tab, const ProbeTabs& L) {
+  const uint32_t n = q.n;
+  const uint32_t j = i + d;
+  const uint32_t od = tri_off(n, d) + i;
+  const float qb_ij = valid ? q.m[M_QB][od] : kNegInf;
+  const bool paired = qb_ij > kNegInf;
+  // wave-uniform early out
+  if (__ballot(paired) == 0ull) return;
+  float p = kNegInf;
+  float sa = kNegInf;
+  float mun = 0.f;
+  if (paired) {
+    const float qa_ij = q.m[M_QA][od];
+    const float* z = q.m[M_Z];
+    const float ztot = z[tri_off(n, n - 1)];
+    const float zl = (i < 1) ? 0.f : z[tri_off(n, i - 1)];                  // Z[0][i-1]
+    const float zr = (j > n - 2) ? 0.f : z[tri_off(n, n - 2 - j) + j + 1];  // Z[j+1][n-1]
+    if (CONTRA) {
+      p = zl + zr + qa_ij + b.params->contra.external_score_basepair - ztot;
+      sa = qa_ij + b.params->contra.multibranch_score_basepair;
+    } else {
+      p = zl + qa_ij + zr - ztot;
+      sa = qa_ij + b.params->turner.coeff_num_branches;
+    }
+  }
+  // enclosing pairs (k,l) = (i-1-a, j+1+bb), a ascending (k descending), bb ascending,
+  // a + bb <= 30, k >= 0, l <= n-1; rows with d+2+a > n-1 have no diagonal left
+  if (d + 2 < n) {
+    const uint32_t lim = min(static_cast<uint32_t>(RNAMC_MAX_2LOOP_LEN), n - 3 - d);
+    p = probe_fold<CONTRA, true>(b, q, d, i, paired, lim, p, qb_ij, tab, L);
+  }
+  if (CONTRA) mun = b.params->contra.multibranch_score_unpair;
+  // multibranch contexts, k = 0..i-1 (594-601 / 701-714):
+  //   x  = sums_1ormore_basepairs[k+1][i-1]  row-major row k+1 (empty when k+1 > i-1)
+  //   y2 = probs_multibranch2[k][j], y = probs_multibranch[k][j]   row-major row k
+  // a lane that is no pair, or is past its own i, folds -inf terms (no-ops).
+  const float* __restrict__ q1r = q.m[M_Q1R];
+  const float* __restrict__ pmr = q.m[M_PM];
+  const float* __restrict__ pm2r = q.m[M_PM2];
+  const uint32_t iend = paired ? i : 0u;
+  const uint32_t i4 = i * 4u;
+  // (i-1)-(k+1) = i - (k+2) >= 0 on the taken path: fold the -(k+2) into the uniform base
+  auto ld_x = [&](uint32_t k) {
+    return (k + 2 <= iend) ? ldu(q1r + tri_off(n, k + 1) - (k + 2), i4) : kNegInf;
+  };
+  auto ld_y = [&](uint32_t k) { return (k < iend) ? ldu(pmr + tri_off(n, k) + d - k, i4) : kNegInf; };
+  auto ld_y2 = [&](uint32_t k) { return (k < iend) ? ldu(pm2r + tri_off(n, k) + d - k, i4) : kNegInf; };
+  auto step = [&](float x, float y, float y2, uint32_t k) {
+    p = lse(p, sa + y2 + x, tab);
+    if (CONTRA) {
+      p = lse(p, sa + y + mun * static_cast<float>(i - k - 1), tab);
+    } else {
+      p = lse(p, sa + y, tab);
+    }
+    p = lse(p, sa + x + y, tab);
+  };
+  uint32_t k = 0;
+  if (imax_wave >= kU) {
+    float xs[kU], ys[kU], y2s[kU];
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      xs[u] = ld_x(k + u);
+      ys[u] = ld_y(k + u);
+      y2s[u] = ld_y2(k + u);
+    }
+    while (k + kU <= imax_wave) {
+      float xs2[kU], ys2[kU], y2s2[kU];
+#pragma unroll
+      for (int u = 0; u < kU; u++) {
+        xs2[u] = xs[u];
+        ys2[u] = ys[u];
+        y2s2[u] = y2s[u];
+      }
+      const uint32_t kn = k + kU;
+      if (kn + kU <= imax_wave) {
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+          xs[u] = ld_x(kn + u);
+          ys[u] = ld_y(kn + u);
+          y2s[u] = ld_y2(kn + u);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kU; u++) step(xs2[u], ys2[u], y2s2[u], k + u);
+      k = kn;
+    }
+  }
+  for (; k < imax_wave; k++) step(ld_x(k), ld_y(k), ld_y2(k), k);
+  if (paired && p > kNegInf) {
+    q.out[od] = p;
+    q.m[M_W][od] = p + q.m[M_MBC][od] - qb_ij;
+  }
+}
+
+// One launch of the outside sweep on diagonal d: blocks [0, blocks_mb) fold
+// probs_multibranch{,2}, the rest compute the pair probabilities.  Both read
+// only results of longer spans, so they are independent within the launch.
+template <bool CONTRA>
+__global__ void __launch_bounds__(256) k_outside(DeviceBatch b, uint32_t d, uint32_t blocks_mb) {
+  __shared__ float4 tab[8];
+  __shared__ ProbeTabs L;
+  load_lse_table(tab);
   const Seq q = load_seq(b, blockIdx.y);
   const uint32_t n = q.n;
   if (d >= n) return;
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n - d) return;
-  const uint32_t j = i + d;
-  const uint8_t* s = q.s;
-  const float* q1d = q.m[M_Q1D];
-  const float* w = q.m[M_W];
-
-  // probs_multibranch / probs_multibranch2: k = j + t over pairs (i,k)
-  float pm = kNegInf, pm2 = kNegInf;
-  {
-    const float mun = CONTRA ? b.params->contra.multibranch_score_unpair : 0.f;
-    const uint32_t cnt = n - 1 - j;
-    for (uint32_t t = 1; t <= cnt; t++) {
-      const float x = w[tri_off(n, d + t) + i];  // -inf when (i,k) is no pair
-      // sums_1ormore_basepairs[j+1][k-1]; for t == 1 that is the empty interval
-      const float r = (t >= 2) ? q1d[tri_off(n, t - 2) + j + 1] : kNegInf;
-      pm = lse(pm, x + r);
-      if (CONTRA) {
-        pm2 = lse(pm2, x + mun * static_cast<float>(t - 1));
-      } else {
-        pm2 = lse(pm2, x);
-      }
-    }
-  }
-  const uint32_t orow = tri_off(n, i) + d;
-  q.m[M_PM][orow] = pm;
-  q.m[M_PM2][orow] = pm2;
-
-  const uint32_t od = tri_off(n, d) + i;
-  const float qb_ij = q.m[M_QB][od];
-  if (!(qb_ij > kNegInf)) return;
-  const auto model = ModelOf<CONTRA>::make(b);
-  const float qa_ij = q.m[M_QA][od];
-  const float* z = q.m[M_Z];
-  const float ztot = z[tri_off(n, n - 1)];
-  const float zl = (i < 1) ? 0.f : z[tri_off(n, i - 1)];                           // Z[0][i-1]
-  const float zr = (j > n - 2) ? 0.f : z[tri_off(n, n - 2 - j) + j + 1];           // Z[j+1][n-1]
-  float p;
-  if (CONTRA) {
-    p = zl + zr + qa_ij + b.params->contra.external_score_basepair - ztot;
+  const uint32_t cells = n - d;
+  const uint32_t bx = (blockIdx.x < blocks_mb) ? blockIdx.x : blockIdx.x - blocks_mb;
+  if (bx > (cells - 1) / blockDim.x) return;  // block past the diagonal (uniform)
+  if (blockIdx.x >= blocks_mb) load_probe_tabs<CONTRA, true>(L, b.params);
+  const uint32_t i = bx * blockDim.x + threadIdx.x;
+  const uint32_t wave_first = i - (threadIdx.x & 63u);  // lane 0 of this wave
+  if (wave_first >= cells) return;                       // whole wave has no cell
+  const bool valid = i < cells;
+  if (blockIdx.x < blocks_mb) {
+    // the first lane of the wave has the longest walk: n-1-j with j = i+d
+    const uint32_t cnt_wave = n - 1 - d - wave_first;
+    outside_mb_cell<CONTRA>(b, q, d, i, valid, cnt_wave, tab);
   } else {
-    p = zl + qa_ij + zr - ztot;
-  }
-  // enclosing pairs (k,l) = (i-1-a, j+1+bb), a ascending (k descending), bb ascending,
-  // a + bb <= 30
-  {
-    const float* qb = q.m[M_QB];
-    const float* lp = q.out;
-    const uint32_t amax = min(static_cast<uint32_t>(RNAMC_MAX_2LOOP_LEN), i == 0 ? 0u : i - 1);
-    if (i > 0) {
-      for (uint32_t a = 0; a <= amax; a++) {
-        const uint32_t k = i - 1 - a;
-        for (uint32_t bb = 0; bb <= RNAMC_MAX_2LOOP_LEN - a; bb++) {
-          const uint32_t l = j + 1 + bb;
-          if (l >= n) break;
-          const uint32_t o = tri_off(n, l - k) + k;
-          const float x = qb[o];
-          if (x > kNegInf) {
-            const float y = model.twoloop(s, k, l, i, j, a, bb);
-            p = lse(p, lp[o] + qb_ij - x + y);
-          }
-        }
-      }
-    }
-  }
-  // multibranch contexts: k = 0..i-1 closes nothing here; (k, l>j) pairs were
-  // folded into probs_multibranch{,2}[k][j]
-  {
-    const float* q1r = q.m[M_Q1R];
-    const float* pmr = q.m[M_PM];
-    const float* pm2r = q.m[M_PM2];
-    float sa;
-    float mun = 0.f;
-    if (CONTRA) {
-      sa = qa_ij + b.params->contra.multibranch_score_basepair;
-      mun = b.params->contra.multibranch_score_unpair;
-    } else {
-      sa = qa_ij + b.params->turner.coeff_num_branches;
-    }
-    for (uint32_t k = 0; k < i; k++) {
-      const uint32_t rk = tri_off(n, k);
-      // sums_1ormore_basepairs[k+1][i-1]; empty interval when k+1 > i-1
-      const float x = (k + 2 <= i) ? q1r[tri_off(n, k + 1) + (i - 1) - (k + 1)] : kNegInf;
-      const float y2 = pm2r[rk + j - k];
-      const float y = pmr[rk + j - k];
-      p = lse(p, sa + y2 + x);
-      if (CONTRA) {
-        p = lse(p, sa + y + mun * static_cast<float>(i - k - 1));
-      } else {
-        p = lse(p, sa + y);
-      }
-      p = lse(p, sa + x + y);
-    }
-  }
-  if (p > kNegInf) {
-    q.out[od] = p;
-    q.m[M_W][od] = p + q.m[M_MBC][od] - qb_ij;
+    // the last valid lane of the wave has the longest walk: i
+    const uint32_t last = min(wave_first + 63u, cells - 1u);
+    outside_pair_cell<CONTRA>(b, q, d, i, valid, last, tab, L);
   }
 }
 
@@ -592,10 +824,6 @@ __global__ void k_finalize(DeviceBatch b) {
 // ----------------------------------------------------------------------------
 // launch wrappers (host)
 
-static inline dim3 diag_grid(uint32_t cells, uint32_t block, uint32_t nseq) {
-  return dim3((cells + block - 1) / block, nseq, 1);
-}
-
 void launch_init(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st) {
   const uint64_t elems = static_cast<uint64_t>(max_n) * (max_n + 1) / 2 * M_COUNT;
   uint32_t gx = static_cast<uint32_t>(std::min<uint64_t>((elems + 1023) / 1024, 512));
@@ -603,25 +831,33 @@ void launch_init(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, hipStream_
   hipLaunchKernelGGL(k_init, dim3(gx, nseq, 1), dim3(256), 0, st, b);
 }
 
-void launch_inside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t cells, uint32_t nseq,
-                   uint32_t block, hipStream_t st) {
-  const dim3 g = diag_grid(cells, block, nseq);
+// sums of diagonal d (if do_sums) and closing-pair block of diagonal d+1 (if do_pair)
+void launch_inside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
+                   uint32_t block, bool do_sums, bool do_pair, hipStream_t st) {
+  const uint32_t cells_s = (do_sums && d < max_n) ? max_n - d : 0;
+  const uint32_t cells_p = (do_pair && d + 1 < max_n) ? max_n - d - 1 : 0;
+  const uint32_t bs = (cells_s + block - 1) / block;
+  const uint32_t bp = (cells_p + block - 1) / block;
+  if (bs + bp == 0 || nseq == 0) return;
+  const dim3 g(bs + bp, nseq, 1);
   if (contra) {
-    hipLaunchKernelGGL(k_inside_pair<true>, g, dim3(block), 0, st, b, d);
-    hipLaunchKernelGGL(k_inside_sums<true>, g, dim3(block), 0, st, b, d);
+    hipLaunchKernelGGL(k_inside<true>, g, dim3(block), 0, st, b, d, bs, do_sums ? 1 : 0,
+                       do_pair ? 1 : 0);
   } else {
-    hipLaunchKernelGGL(k_inside_pair<false>, g, dim3(block), 0, st, b, d);
-    hipLaunchKernelGGL(k_inside_sums<false>, g, dim3(block), 0, st, b, d);
+    hipLaunchKernelGGL(k_inside<false>, g, dim3(block), 0, st, b, d, bs, do_sums ? 1 : 0,
+                       do_pair ? 1 : 0);
   }
 }
 
-void launch_outside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t cells, uint32_t nseq,
+void launch_outside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
                     uint32_t block, hipStream_t st) {
-  const dim3 g = diag_grid(cells, block, nseq);
+  if (d >= max_n || nseq == 0) return;
+  const uint32_t nb = (max_n - d + block - 1) / block;
+  const dim3 g(2 * nb, nseq, 1);
   if (contra) {
-    hipLaunchKernelGGL(k_outside<true>, g, dim3(block), 0, st, b, d);
+    hipLaunchKernelGGL(k_outside<true>, g, dim3(block), 0, st, b, d, nb);
   } else {
-    hipLaunchKernelGGL(k_outside<false>, g, dim3(block), 0, st, b, d);
+    hipLaunchKernelGGL(k_outside<false>, g, dim3(block), 0, st, b, d, nb);
   }
 }
 
