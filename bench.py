@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the McCaskill bpp hot path on MI355X.
+
+Contract (one JSON line from rank 0):
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (inside + outside sweep + final map) over the
+whole workload, inputs already resident in HBM, outputs left in HBM.  The default
+workload is BASELINE.json's batch config: 10 000 synthetic RNAs of length 256..2048
+(SplitMix64, master seed 10000), Turner-2004-shaped synthetic tables, reference-order
+(bit-faithful) summation.  With N GPUs the batch is sharded by longest-processing-time
+over sum n(n^2-1)/6 (strong scaling: total work fixed); no data-path collective — the
+only communication is the barrier and the max-over-ranks of the step time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def shard_lpt(costs, world):
+    """Longest-processing-time assignment of units to `world` ranks.
+    Returns a list of index arrays (one per rank)."""
+    order = np.argsort(-np.asarray(costs, dtype=np.float64), kind="stable")
+    loads = np.zeros(world)
+    shards = [[] for _ in range(world)]
+    for idx in order:
+        r = int(np.argmin(loads))
+        shards[r].append(int(idx))
+        loads[r] += costs[idx]
+    return [np.array(s, dtype=np.int64) for s in shards]
+
+
+def build_workload(name, batch_count):
+    from rna_algos_amd import workloads as W
+    if name == "batch10k":
+        lens = W.batch_lengths(batch_count)
+        seqs = [W.synthetic_seq(int(lens[s]), (10000 << 32) + s) for s in range(batch_count)]
+        label = f"{batch_count} synthetic RNAs, length 256..2048 (SplitMix64 master seed 10000)"
+    elif name == "n4096":
+        seqs = [W.synthetic_seq(4096, 4096)]
+        label = "single synthetic n=4096 RNA (seed 4096)"
+    elif name == "n1024":
+        seqs = [W.synthetic_seq(1024, 1024)]
+        label = "single synthetic n=1024 RNA (seed 1024)"
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    return seqs, label
+
+
+def outside_bytes(lengths, f):
+    """Algorithmic bytes of the outside sweep (the dominant kernel): L_d 8 B per (cell,k),
+    L_e 12 B per (paired cell,k), 8 B per enclosing-pair probe, 4 packed triangles written."""
+    from rna_algos_amd import workloads as W
+    lengths = np.asarray(lengths, dtype=np.float64)
+    T = W.pair_cost(lengths).sum()
+    n2 = (lengths * lengths).sum()
+    return (8.0 + 12.0 * f) * T + 8.0 * 496.0 * f * n2 / 2.0 + 16.0 * n2 / 2.0
+
+
+def inside_bytes(lengths, f, contra):
+    from rna_algos_amd import workloads as W
+    lengths = np.asarray(lengths, dtype=np.float64)
+    T = W.pair_cost(lengths).sum()
+    n2 = (lengths * lengths).sum()
+    return (16.0 + (4.0 if contra else 0.0)) * T + 4.0 * 496.0 * f * n2 / 2.0 + 20.0 * n2 / 2.0
+
+
+def cpu_baseline(params, seqs, contra, budget_s):
+    """Oracle ("port" of the reference's CPU path) on a bounded, length-stratified sample,
+    one sequence per thread on all host cores (as the reference's thread pool does)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from rna_algos_amd import workloads as W
+    # a 1-GPU box's CPU share is 16 cores; never more threads than that
+    cores = min(os.cpu_count() or 1, 16)
+    lens = np.array([len(s) for s in seqs])
+    order = np.argsort(lens)
+    # ~150 ns per (cell,k) per core measured for the dense row-major restatement
+    target_T = budget_s * cores / 150e-9
+    k = max(1, min(len(seqs), cores))
+    pick = order[np.linspace(0, len(order) - 1, k).astype(int)]
+    while k > 1 and W.pair_cost(lens[pick]).sum() > target_T:
+        k -= 1
+        pick = order[np.linspace(0, len(order) - 1, k).astype(int)]
+    sample = [seqs[i] for i in pick]
+    if W.pair_cost(lens[pick]).sum() > 4 * target_T and len(sample) == 1:
+        # a single very long sequence (n=4096): time a shorter prefix instead
+        m = int((target_T * 6) ** (1 / 3))
+        sample = [sample[0][:m]]
+    t0 = time.time()
+    O.bpp_batch(params.ptr, sample, contra, False, n_threads=min(cores, len(sample)),
+                want_bpp=False)
+    dt = time.time() - t0
+    nt = int(sum(len(s) for s in sample))
+    T = float(W.pair_cost(np.array([len(s) for s in sample])).sum())
+    T_all = float(W.pair_cost(lens).sum())
+    return {
+        "value": nt / dt, "unit": "nt/s", "cores": int(min(cores, len(sample))),
+        "kind": "port",
+        "sample": f"{len(sample)} sequences (lengths {sorted(len(s) for s in sample)}) of the "
+                  f"workload, {dt:.1f} s; faster than the Rust reference would be (dense arrays, "
+                  f"no twoloop_scores map)",
+        "ns_per_cell_k": dt * 1e9 / T,
+        "extrapolated_workload_nt_per_s": float(lens.sum()) / (dt * T_all / T),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="batch10k", choices=["batch10k", "n4096", "n1024"])
+    ap.add_argument("--model", default="turner", choices=["turner", "contra"])
+    ap.add_argument("--batch-count", type=int, default=10000)
+    ap.add_argument("--group-max-seqs", type=int, default=0)
+    ap.add_argument("--param-seed", type=int, default=1)
+    ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from rna_algos_amd import workloads as W
+    from rna_algos_amd.utils import FoldScoreSets
+    from rna_algos_amd.mccaskill_algo import Context
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    contra = args.model == "contra"
+
+    seqs, label = build_workload(args.workload, args.batch_count)
+    lens_all = np.array([len(s) for s in seqs], dtype=np.int64)
+    costs = W.pair_cost(lens_all)
+    if len(seqs) >= world:
+        mine = shard_lpt(costs, world)[rank]
+    else:  # fewer units than ranks (single-sequence workloads): replicas
+        mine = np.arange(len(seqs))
+    my_seqs = [seqs[i] for i in mine]
+    lens = lens_all[mine].astype(np.uint64)
+    offsets = np.zeros(len(my_seqs) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=offsets[1:])
+    out_offsets = np.zeros(len(my_seqs) + 1, dtype=np.uint64)
+    np.cumsum(lens * (lens + np.uint64(1)) // np.uint64(2), out=out_offsets[1:])
+
+    params = FoldScoreSets.synthetic(args.param_seed)
+    ctx = Context(params, device=local_rank)
+    ctx.set("profile", 1)
+    if args.group_max_seqs:
+        ctx.set("group_max_seqs", args.group_max_seqs)
+
+    # inputs resident in HBM before the timed region; outputs stay in HBM
+    d_bases = torch.from_numpy(np.concatenate(my_seqs)).to(dev)
+    d_out = torch.empty(int(out_offsets[-1]), dtype=torch.float32, device=dev)
+    d_logz = torch.empty(len(my_seqs), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.bpp_batch_device(len(my_seqs), d_bases.data_ptr(), offsets, contra, False,
+                             d_out.data_ptr(), out_offsets, d_logz.data_ptr(), stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    ms_in = ms_out = 0.0
+    l_in = l_out = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        st = ctx.stats()  # event-timed sweeps of this step (the call synchronised its stream)
+        ms_in += st["ms_inside"]
+        ms_out += st["ms_outside"]
+        l_in += st["launches_inside"]
+        l_out += st["launches_outside"]
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: the result is a probability matrix (cheap, outside the timed region)
+    probe = d_out[: min(d_out.numel(), 1 << 22)]
+    pres = probe[probe >= -0.5]
+    assert pres.numel() > 0 and float(pres.min()) >= -0.001 and float(pres.max()) < 1.05
+    assert bool(torch.isfinite(d_logz).all())
+
+    if rank == 0:
+        total_nt = int(lens_all.sum()) if len(seqs) >= world else int(lens_all.sum()) * world
+        steps = max(args.steps, 1)
+        f = float(np.mean([W.paired_fraction(s) for s in my_seqs[:: max(1, len(my_seqs) // 8)]]))
+        b_out = outside_bytes(lens.astype(np.float64), f)
+        b_in = inside_bytes(lens.astype(np.float64), f, contra)
+        avg_out_ms = ms_out / max(l_out, 1)
+        avg_in_ms = ms_in / max(l_in, 1)
+        ach_out = b_out * steps / (ms_out * 1e-3) / 1e9 if ms_out > 0 else 0.0
+        ach_in = b_in * steps / (ms_in * 1e-3) / 1e9 if ms_in > 0 else 0.0
+        res = {
+            "metric": "nucleotides/sec (batch)" if args.workload == "batch10k" else "nucleotides/sec",
+            "value": total_nt * steps / elapsed,
+            "unit": "nt/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": label,
+                "model": "Turner-2004-shaped synthetic tables" if not contra
+                         else "CONTRAfold-shaped synthetic tables",
+                "tables": f"synthetic seed {args.param_seed} (real tables live in the absent "
+                          f"rna-ss-params crate)",
+                "summation": "reference-order (bit-faithful to the CPU path)",
+                "allows_short_hairpins": False,
+                "sharding": f"LPT over sum n(n^2-1)/6, {world} rank(s), no data-path collective",
+                "sequences_rank0": len(my_seqs),
+                "paired_fraction_f": f,
+            },
+            "roofline": {
+                "kernel": "k_outside (outside sweep, one launch per anti-diagonal)",
+                "bound": "hbm",
+                "achieved": ach_out,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": ach_out / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": b_out / max(l_out / steps, 1),
+                "avg_launch_ms": avg_out_ms,
+                "launches_per_step": l_out // steps,
+            },
+            "roofline_inside": {
+                "kernel": "k_inside (inside sweep)", "bound": "hbm", "achieved": ach_in,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_in / HBM_PEAK_GBS,
+                "avg_launch_ms": avg_in_ms, "launches_per_step": l_in // steps,
+            },
+        }
+        if args.workload != "batch10k":
+            res["ms_per_seq"] = elapsed * 1e3 / steps
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(params, my_seqs, contra, args.cpu_budget_s)
+        print(json.dumps(res), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

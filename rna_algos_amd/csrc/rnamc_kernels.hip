@@ -41,8 +41,11 @@ constexpr int kU = 8;  // k-steps fetched ahead per lane
 // ----------------------------------------------------------------------------
 // numerics: src/utils.rs:579-655
 
-// coefficient rows of ln_exp_1p (src/utils.rs:602-627), piece 0..7 by ascending x
-__constant__ float kLseCoef[8][4] = {
+// ln_exp_1p (src/utils.rs:602-627) is an 8-piece cubic; piece 8 below is the
+// identity (0,0,1,0): ((0*z+0)*z+1)*z+0 == z exactly, which is what logsumexp
+// adds when z >= LOGSUMEXP_THRESHOLD_UPPER (src/utils.rs:589-591).
+constexpr int kLsePieces = 9;
+__constant__ float kLseCoef[kLsePieces][4] = {
     {-0.0065591595f, 0.12764427f, 0.49965546f, 0.6931542f},
     {-0.015515756f, 0.14467756f, 0.48829398f, 0.6958093f},
     {-0.012890925f, 0.13010283f, 0.51503986f, 0.6795586f},
@@ -51,12 +54,46 @@ __constant__ float kLseCoef[8][4] = {
     {-0.0010110698f, 0.018594341f, 0.88317305f, 0.25236955f},
     {-0.000196278f, 0.0046084408f, 0.9634432f, 0.09831489f},
     {-0.0000113994f, 0.0003734731f, 0.9959107f, 0.0149855051f},
+    {0.f, 0.f, 1.f, 0.f},
+};
+// upper bounds of pieces 0..7 (`x < t` picks the lower piece)
+__constant__ float kLseBreaks[8] = {0.66153675f, 1.6320158f, 2.4912589f, 3.3792500f,
+                                    4.426169f,   5.789071f,  7.8162727f, 11.862479f};
+
+// Piece lookup without a compare ladder: the top 12 bits of z (sign, exponent,
+// 3 mantissa bits) select one of 42 cells covering [0, 0.5), the 40 eighth-binade
+// cells of [0.5, 16) and [16, inf); no cell holds more than one breakpoint, so a
+// cell entry {breakpoint or +inf, byte offset of the lower piece} and ONE compare
+// give the piece.  LDS image: 9 coefficient rows (144 B) then 42 cell entries.
+constexpr int kLseCells = 42;
+constexpr int kLseCellLo = 0x3F0 - 1;  // (bits(0.5f) >> 20) - 1
+constexpr int kLseCellHi = 0x418;      //  bits(16.f) >> 20
+struct LseTab {
+  float4 coef[kLsePieces];
+  float2 cell[kLseCells];  // {threshold, byte offset of lower piece as float bits}
 };
 
-__device__ __forceinline__ void load_lse_table(float4* tab) {
-  if (threadIdx.x < 8) {
-    tab[threadIdx.x] = make_float4(kLseCoef[threadIdx.x][0], kLseCoef[threadIdx.x][1],
-                                   kLseCoef[threadIdx.x][2], kLseCoef[threadIdx.x][3]);
+__device__ __forceinline__ void load_lse_table(LseTab* tab) {
+  const uint32_t t = threadIdx.x;
+  if (t < kLsePieces)
+    tab->coef[t] = make_float4(kLseCoef[t][0], kLseCoef[t][1], kLseCoef[t][2], kLseCoef[t][3]);
+  if (t < kLseCells) {
+    // cell t covers [lo, hi)
+    float lo, hi;
+    if (t == 0) {
+      lo = 0.f, hi = 0.5f;
+    } else if (t == kLseCells - 1) {
+      lo = 16.f, hi = __builtin_inff();
+    } else {
+      lo = __uint_as_float(static_cast<uint32_t>(kLseCellLo + static_cast<int>(t)) << 20);
+      hi = __uint_as_float(static_cast<uint32_t>(kLseCellLo + static_cast<int>(t) + 1) << 20);
+    }
+    // piece of `lo`: number of breakpoints <= lo
+    int piece = 0;
+    for (int x = 0; x < 8; x++) piece += (lo >= kLseBreaks[x]) ? 1 : 0;
+    float thr = __builtin_inff();
+    if (piece < 8 && kLseBreaks[piece] < hi) thr = kLseBreaks[piece];
+    tab->cell[t] = make_float2(thr, __uint_as_float(static_cast<uint32_t>(piece) * 16u));
   }
   __syncthreads();
 }
@@ -78,21 +115,16 @@ __device__ __forceinline__ float vmin(float a, float b) {
 // map entries are -inf and are masked at the source), so the reference's two
 // is_finite() early-outs collapse to "if the smaller one is -inf take the
 // larger one".  Piece boundaries: `x < t` in the reference <=> !(z >= t).
-__device__ __forceinline__ float lse(float sum, float x, const float4* tab) {
+__device__ __forceinline__ float lse(float sum, float x, const LseTab* tab) {
   const float hi = vmax(sum, x);
   const float lo = vmin(sum, x);
-  const float z = hi - lo;
-  const bool c1 = z >= 3.3792500f;
-  const float tmid = c1 ? 5.789071f : 1.6320158f;
-  const float tlo = c1 ? 4.426169f : 0.66153675f;
-  const float thi = c1 ? 7.8162727f : 2.4912589f;
-  const bool c2 = z >= tmid;
-  const float t3 = c2 ? thi : tlo;
-  const bool c3 = z >= t3;
-  const unsigned boff = (c1 ? 64u : 0u) | (c2 ? 32u : 0u) | (c3 ? 16u : 0u);
+  const float z = hi - lo;  // >= 0, or +inf / NaN when lo is -inf (result then discarded)
+  const int e = static_cast<int>(__float_as_uint(z) >> 20);
+  const int cell = min(max(e, kLseCellLo), kLseCellHi) - kLseCellLo;  // v_med3_i32
+  const float2 ce = tab->cell[cell];
+  const uint32_t boff = __float_as_uint(ce.y) + ((z >= ce.x) ? 16u : 0u);
   const float4 co = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tab) + boff);
   float r = ((co.x * z + co.y) * z + co.z) * z + co.w;
-  r = (z >= 11.862479f) ? z : r;
   r = lo + r;
   return (lo == kNegInf) ? hi : r;
 }
@@ -425,7 +457,7 @@ __global__ void k_init(DeviceBatch b) {
 // (src/mccaskill_algo.rs:297-343 Turner, 400-467 CONTRAfold)
 template <bool CONTRA>
 __device__ __forceinline__ void inside_pair_cell(const DeviceBatch& b, const Seq& q, uint32_t d,
-                                                 uint32_t i, bool valid, const float4* tab,
+                                                 uint32_t i, bool valid, const LseTab* tab,
                                                  const ProbeTabs& L) {
   const uint32_t n = q.n;
   const uint32_t j = i + d;
@@ -461,7 +493,7 @@ __device__ __forceinline__ void inside_pair_cell(const DeviceBatch& b, const Seq
 // (src/mccaskill_algo.rs:344-374 Turner, 468-512 CONTRAfold)
 template <bool CONTRA>
 __device__ __forceinline__ void inside_sums_cell(const DeviceBatch& b, const Seq& q, uint32_t d,
-                                                 uint32_t i, const float4* tab) {
+                                                 uint32_t i, const LseTab* tab) {
   const uint32_t n = q.n;
   const uint32_t od = tri_off(n, d) + i;  // this cell, diag-major
   const float* __restrict__ zre = q.m[M_ZRE];
@@ -584,9 +616,10 @@ __device__ __forceinline__ void inside_sums_cell(const DeviceBatch& b, const Seq
 template <bool CONTRA>
 __global__ void __launch_bounds__(256) k_inside(DeviceBatch b, uint32_t d, uint32_t blocks_sums,
                                                 int do_sums, int do_pair) {
-  __shared__ float4 tab[8];
+  __shared__ LseTab tabs;
   __shared__ ProbeTabs L;
-  load_lse_table(tab);
+  const LseTab* tab = &tabs;
+  load_lse_table(&tabs);
   const Seq q = load_seq(b, blockIdx.y);
   const uint32_t n = q.n;
   if (blockIdx.x < blocks_sums) {
@@ -614,7 +647,7 @@ __global__ void __launch_bounds__(256) k_inside(DeviceBatch b, uint32_t d, uint3
 template <bool CONTRA>
 __device__ __forceinline__ void outside_mb_cell(const DeviceBatch& b, const Seq& q, uint32_t d,
                                                 uint32_t i, bool valid, uint32_t cnt_wave,
-                                                const float4* tab) {
+                                                const LseTab* tab) {
   const uint32_t n = q.n;
   const uint32_t j = i + d;
   const float* __restrict__ q1d = q.m[M_Q1D];
@@ -678,7 +711,7 @@ __device__ __forceinline__ void outside_mb_cell(const DeviceBatch& b, const Seq&
 template <bool CONTRA>
 __device__ __forceinline__ void outside_pair_cell(const DeviceBatch& b, const Seq& q, uint32_t d,
                                                   uint32_t i, bool valid, uint32_t imax_wave,
-                                                  const float4* tab, const ProbeTabs& L) {
+                                                  const LseTab* tab, const ProbeTabs& L) {
   const uint32_t n = q.n;
   const uint32_t j = i + d;
   const uint32_t od = tri_off(n, d) + i;
@@ -777,9 +810,10 @@ __device__ __forceinline__ void outside_pair_cell(const DeviceBatch& b, const Se
 // only results of longer spans, so they are independent within the launch.
 template <bool CONTRA>
 __global__ void __launch_bounds__(256) k_outside(DeviceBatch b, uint32_t d, uint32_t blocks_mb) {
-  __shared__ float4 tab[8];
+  __shared__ LseTab tabs;
   __shared__ ProbeTabs L;
-  load_lse_table(tab);
+  const LseTab* tab = &tabs;
+  load_lse_table(&tabs);
   const Seq q = load_seq(b, blockIdx.y);
   const uint32_t n = q.n;
   if (d >= n) return;

@@ -251,7 +251,7 @@ struct ProbeFixed {
 template <bool CONTRA, bool OUTSIDE>
 __device__ __forceinline__ float probe_fold(const DeviceBatch& b, const Seq& q, uint32_t d,
                                             uint32_t i, bool act, uint32_t lim, float sum,
-                                            float qb_ij, const float4* tab, const ProbeTabs& L) {
+                                            float qb_ij, const LseTab* tab, const ProbeTabs& L) {
   const uint32_t n = q.n;
   const uint32_t j = i + d;
   const float* __restrict__ qb = q.m[M_QB];

@@ -72,10 +72,12 @@ def main():
             lens = batch_lengths(10000)[:cnt]
             rng = np.random.default_rng(5)
             seqs = [rng.integers(0, 4, n).astype(np.uint8) for n in lens]
-            for gm in (64, 256, 1024):
+            gms = [int(x) for x in os.environ.get("GSIZES", "256,1024").split(",")]
+            for gm in gms:
                 ctx.set("group_max_seqs", gm)
                 run(ctx, seqs, False, reps=1, label=f"{w} group{gm}")
-            run(ctx, seqs, True, reps=1, label=f"{w} group1024")
+            if os.environ.get("CONTRA", "1") == "1":
+                run(ctx, seqs, True, reps=1, label=f"{w} group{gms[-1]}")
 
 
 if __name__ == "__main__":
