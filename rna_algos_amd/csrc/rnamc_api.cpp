@@ -146,7 +146,9 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
       const uint32_t s = order[x];
       const uint32_t n = static_cast<uint32_t>(offsets[s + 1] - offsets[s]);
       const uint64_t pk_words = ((static_cast<uint64_t>(n) + 160) / 16 + 4 + 63) & ~63ull;
-      const uint64_t need = tri_pad_of(n) * M_COUNT + pk_words;
+      const uint64_t cidx_words = (tri_pad_of(n) + 1) / 2;  // u16 per cell, in 4-byte units
+      const uint64_t ccnt_words = (static_cast<uint64_t>(n) + 63) & ~63ull;
+      const uint64_t need = tri_pad_of(n) * M_COUNT + pk_words + cidx_words + ccnt_words;
       if (cnt > 0 && (cnt >= static_cast<uint32_t>(c->group_max_seqs) || cur + need > ws_cap_floats)) {
         max_group_floats = std::max(max_group_floats, cur);
         cur = 0;
@@ -162,6 +164,8 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
       sd.batch_idx = s;
       sd.pk_words = static_cast<uint32_t>(pk_words);
       sd.pk_off = cur + tri_pad_of(n) * M_COUNT;
+      sd.cidx_off = sd.pk_off + pk_words;
+      sd.ccnt_off = sd.cidx_off + cidx_words;
       c->descs.push_back(sd);
       cur += need;
       cnt++;

@@ -44,6 +44,8 @@ struct SeqDesc {
   uint32_t batch_idx; // position in the caller's batch (for log_partition)
   uint32_t pk_words;  // 32-bit words of the 2-bit packed sequence copy
   uint64_t pk_off;    // float offset of that copy in the workspace
+  uint64_t cidx_off;  // float offset of the u16 lists of canonical cells (one per diagonal)
+  uint64_t ccnt_off;  // float offset of the u32 list lengths (one per diagonal)
 };
 
 }  // namespace rnamc

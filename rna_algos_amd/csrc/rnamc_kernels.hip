@@ -186,6 +186,9 @@ struct Seq {
   float* m[M_COUNT];
   float* out;          // packed bpp triangle (log domain until finalize)
   const uint32_t* pk;  // 2-bit packed bases, 16 per word, position p at bit 2(p+32)
+  // canonical-pair cells of every diagonal, ascending i, at tri_off(n,d); counts per d
+  uint16_t* cidx;
+  uint32_t* ccnt;
 };
 
 __device__ __forceinline__ Seq load_seq(const DeviceBatch& b, uint32_t which) {
@@ -198,6 +201,8 @@ __device__ __forceinline__ Seq load_seq(const DeviceBatch& b, uint32_t which) {
   for (int x = 0; x < M_COUNT; x++) q.m[x] = base + static_cast<size_t>(x) * sd.tri_pad;
   q.out = b.out + sd.out_off;
   q.pk = reinterpret_cast<const uint32_t*>(b.workspace + sd.pk_off);
+  q.cidx = reinterpret_cast<uint16_t*>(b.workspace + sd.cidx_off);
+  q.ccnt = reinterpret_cast<uint32_t*>(b.workspace + sd.ccnt_off);
   return q;
 }
 
@@ -452,6 +457,37 @@ __global__ void k_init(DeviceBatch b) {
   }
 }
 
+// Lists of the cells that can hold a pair: for every diagonal d the ascending i
+// with a canonical (s[i], s[i+d]).  The closing-pair block and the outside pair
+// block run one lane per LISTED cell, so no lane idles on the ~62 % of cells that
+// can never pair.  One wave per (sequence, diagonal).
+__global__ void __launch_bounds__(64) k_compact(DeviceBatch b) {
+  const Seq q = load_seq(b, blockIdx.y);
+  const uint32_t n = q.n;
+  const uint32_t d = blockIdx.x;
+  if (d >= n) return;
+  const uint8_t* s = q.s;
+  uint16_t* dst = q.cidx + tri_off(n, d);
+  const uint32_t lane = threadIdx.x;
+  uint32_t cnt = 0;
+  for (uint32_t i0 = 0; i0 < n - d; i0 += 64) {
+    const uint32_t i = i0 + lane;
+    const bool c = (i < n - d) && canonical(s[i], s[i + d]);
+    const unsigned long long m = __ballot(c);
+    if (c) dst[cnt + __popcll(m & ((1ull << lane) - 1ull))] = static_cast<uint16_t>(i);
+    cnt += static_cast<uint32_t>(__popcll(m));
+  }
+  if (lane == 0) q.ccnt[d] = cnt;
+}
+
+// lane -> listed cell of diagonal d; returns false for lanes past the list
+__device__ __forceinline__ bool listed_cell(const Seq& q, uint32_t d, uint32_t t, uint32_t cnt,
+                                            uint32_t& i) {
+  const bool valid = t < cnt;
+  i = valid ? static_cast<uint32_t>(q.cidx[tri_off(q.n, d) + t]) : 0u;
+  return valid;
+}
+
 // ----------------------------------------------------------------------------
 // inside pass, closing-pair block of one cell of diagonal d
 // (src/mccaskill_algo.rs:297-343 Turner, 400-467 CONTRAfold)
@@ -615,27 +651,34 @@ __device__ __forceinline__ void inside_sums_cell(const DeviceBatch& b, const Seq
 // spans <= d-1) and so runs beside the folds.
 template <bool CONTRA>
 __global__ void __launch_bounds__(256) k_inside(DeviceBatch b, uint32_t d, uint32_t blocks_sums,
-                                                int do_sums, int do_pair) {
+                                                uint32_t nseq, int do_sums, int do_pair) {
   __shared__ LseTab tabs;
   __shared__ ProbeTabs L;
   const LseTab* tab = &tabs;
   load_lse_table(&tabs);
-  const Seq q = load_seq(b, blockIdx.y);
+  // Blocks are dealt round-robin to the 8 XCDs by linear id.  Consecutive ids walk
+  // over SEQUENCES (same role, same cell range), so every XCD receives the same mix
+  // of light and heavy blocks whatever the grid width is.
+  const uint32_t bxr = blockIdx.x / nseq;           // role + cell-range index
+  const uint32_t which = blockIdx.x - bxr * nseq;   // sequence
+  const Seq q = load_seq(b, which);
   const uint32_t n = q.n;
-  if (blockIdx.x < blocks_sums) {
+  if (bxr < blocks_sums) {
     if (!do_sums || d >= n) return;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = bxr * blockDim.x + threadIdx.x;
     if (i >= n - d) return;
     inside_sums_cell<CONTRA>(b, q, d, i, tab);
   } else {
     const uint32_t dp = d + 1;
     if (!do_pair || dp >= n) return;  // uniform over the block
-    const uint32_t i = (blockIdx.x - blocks_sums) * blockDim.x + threadIdx.x;
-    const uint32_t wave_first = i - (threadIdx.x & 63u);
-    if (blockIdx.x - blocks_sums > (n - dp - 1) / blockDim.x) return;  // block past the diagonal
+    const uint32_t cnt = q.ccnt[dp];
+    const uint32_t t = (bxr - blocks_sums) * blockDim.x + threadIdx.x;
+    if ((bxr - blocks_sums) * blockDim.x >= cnt) return;  // block past the list
     load_probe_tabs<CONTRA, false>(L, b.params);
-    if (wave_first >= n - dp) return;
-    inside_pair_cell<CONTRA>(b, q, dp, i, i < n - dp, tab, L);
+    if (t - (threadIdx.x & 63u) >= cnt) return;  // wave past the list
+    uint32_t i;
+    const bool valid = listed_cell(q, dp, t, cnt, i);
+    inside_pair_cell<CONTRA>(b, q, dp, i, valid, tab, L);
   }
 }
 
@@ -809,30 +852,42 @@ __device__ __forceinline__ void outside_pair_cell(const DeviceBatch& b, const Se
 // probs_multibranch{,2}, the rest compute the pair probabilities.  Both read
 // only results of longer spans, so they are independent within the launch.
 template <bool CONTRA>
-__global__ void __launch_bounds__(256) k_outside(DeviceBatch b, uint32_t d, uint32_t blocks_mb) {
+__global__ void __launch_bounds__(256) k_outside(DeviceBatch b, uint32_t d, uint32_t blocks_mb,
+                                                 uint32_t nseq) {
   __shared__ LseTab tabs;
   __shared__ ProbeTabs L;
   const LseTab* tab = &tabs;
   load_lse_table(&tabs);
-  const Seq q = load_seq(b, blockIdx.y);
+  // linear id -> (role block, sequence) as in k_inside; within a role the blocks
+  // with the longest walks are issued first (probs_multibranch: small i; pair
+  // probabilities: large i)
+  const uint32_t bxr = blockIdx.x / nseq;
+  const uint32_t which = blockIdx.x - bxr * nseq;
+  const Seq q = load_seq(b, which);
   const uint32_t n = q.n;
   if (d >= n) return;
   const uint32_t cells = n - d;
-  const uint32_t bx = (blockIdx.x < blocks_mb) ? blockIdx.x : blockIdx.x - blocks_mb;
-  if (bx > (cells - 1) / blockDim.x) return;  // block past the diagonal (uniform)
-  if (blockIdx.x >= blocks_mb) load_probe_tabs<CONTRA, true>(L, b.params);
-  const uint32_t i = bx * blockDim.x + threadIdx.x;
-  const uint32_t wave_first = i - (threadIdx.x & 63u);  // lane 0 of this wave
-  if (wave_first >= cells) return;                       // whole wave has no cell
-  const bool valid = i < cells;
-  if (blockIdx.x < blocks_mb) {
+  if (bxr < blocks_mb) {
+    const uint32_t i = bxr * blockDim.x + threadIdx.x;
+    const uint32_t wave_first = i - (threadIdx.x & 63u);  // lane 0 of this wave
+    if (wave_first >= cells) return;                       // whole wave has no cell
     // the first lane of the wave has the longest walk: n-1-j with j = i+d
     const uint32_t cnt_wave = n - 1 - d - wave_first;
-    outside_mb_cell<CONTRA>(b, q, d, i, valid, cnt_wave, tab);
+    outside_mb_cell<CONTRA>(b, q, d, i, i < cells, cnt_wave, tab);
   } else {
-    // the last valid lane of the wave has the longest walk: i
-    const uint32_t last = min(wave_first + 63u, cells - 1u);
-    outside_pair_cell<CONTRA>(b, q, d, i, valid, last, tab, L);
+    const uint32_t cnt = q.ccnt[d];
+    const uint32_t bx = 2u * blocks_mb - 1u - bxr;  // descending: heavy blocks first
+    if (bx * blockDim.x >= cnt) return;  // block past the list (uniform)
+    load_probe_tabs<CONTRA, true>(L, b.params);
+    const uint32_t t = bx * blockDim.x + threadIdx.x;
+    const uint32_t wave_first = t - (threadIdx.x & 63u);
+    if (wave_first >= cnt) return;
+    uint32_t i;
+    const bool valid = listed_cell(q, d, t, cnt, i);
+    // the last listed lane of the wave has the largest i, i.e. the longest walk
+    const uint32_t last_lane = min(63u, cnt - 1u - wave_first);
+    const uint32_t imax = static_cast<uint32_t>(__shfl(static_cast<int>(i), static_cast<int>(last_lane)));
+    outside_pair_cell<CONTRA>(b, q, d, i, valid, imax, tab, L);
   }
 }
 
@@ -863,6 +918,7 @@ void launch_init(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, hipStream_
   uint32_t gx = static_cast<uint32_t>(std::min<uint64_t>((elems + 1023) / 1024, 512));
   if (gx == 0) gx = 1;
   hipLaunchKernelGGL(k_init, dim3(gx, nseq, 1), dim3(256), 0, st, b);
+  hipLaunchKernelGGL(k_compact, dim3(max_n, nseq, 1), dim3(64), 0, st, b);
 }
 
 // sums of diagonal d (if do_sums) and closing-pair block of diagonal d+1 (if do_pair)
@@ -873,12 +929,12 @@ void launch_inside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n
   const uint32_t bs = (cells_s + block - 1) / block;
   const uint32_t bp = (cells_p + block - 1) / block;
   if (bs + bp == 0 || nseq == 0) return;
-  const dim3 g(bs + bp, nseq, 1);
+  const dim3 g((bs + bp) * nseq, 1, 1);
   if (contra) {
-    hipLaunchKernelGGL(k_inside<true>, g, dim3(block), 0, st, b, d, bs, do_sums ? 1 : 0,
+    hipLaunchKernelGGL(k_inside<true>, g, dim3(block), 0, st, b, d, bs, nseq, do_sums ? 1 : 0,
                        do_pair ? 1 : 0);
   } else {
-    hipLaunchKernelGGL(k_inside<false>, g, dim3(block), 0, st, b, d, bs, do_sums ? 1 : 0,
+    hipLaunchKernelGGL(k_inside<false>, g, dim3(block), 0, st, b, d, bs, nseq, do_sums ? 1 : 0,
                        do_pair ? 1 : 0);
   }
 }
@@ -887,11 +943,11 @@ void launch_outside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_
                     uint32_t block, hipStream_t st) {
   if (d >= max_n || nseq == 0) return;
   const uint32_t nb = (max_n - d + block - 1) / block;
-  const dim3 g(2 * nb, nseq, 1);
+  const dim3 g(2 * nb * nseq, 1, 1);
   if (contra) {
-    hipLaunchKernelGGL(k_outside<true>, g, dim3(block), 0, st, b, d, nb);
+    hipLaunchKernelGGL(k_outside<true>, g, dim3(block), 0, st, b, d, nb, nseq);
   } else {
-    hipLaunchKernelGGL(k_outside<false>, g, dim3(block), 0, st, b, d, nb);
+    hipLaunchKernelGGL(k_outside<false>, g, dim3(block), 0, st, b, d, nb, nseq);
   }
 }
 

@@ -67,6 +67,15 @@ def main():
         elif w == "n4096":
             run(ctx, [O.splitmix_seq(4096, 4096)], False, label="n4096")
             run(ctx, [O.splitmix_seq(4096, 4096)], True, reps=1, label="n4096")
+        elif w.startswith("top"):
+            # the `cnt` longest sequences of the 10k batch: what one lock-step group really holds
+            cnt = int(w[3:])
+            from rna_algos_amd import workloads as WL
+            lens = WL.batch_lengths(10000)
+            order = np.argsort(-lens, kind="stable")[:cnt]
+            seqs = [WL.synthetic_seq(int(lens[s]), (10000 << 32) + int(s)) for s in order]
+            ctx.set("group_max_seqs", cnt)
+            run(ctx, seqs, False, reps=1, label=w)
         elif w.startswith("batch"):
             cnt = int(w[5:])
             lens = batch_lengths(10000)[:cnt]
