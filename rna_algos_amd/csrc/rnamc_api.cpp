@@ -68,8 +68,9 @@ struct DeviceGuard {
 };
 
 uint64_t tri_pad_of(uint32_t n) {
+  // + 64 floats: kernels read up to one wave past a diagonal's end (values masked)
   uint64_t t = static_cast<uint64_t>(n) * (n + 1ull) / 2ull;
-  return (t + 63ull) & ~63ull;
+  return ((t + 63ull) & ~63ull) + 64ull;
 }
 
 int ensure_hp_init(rnamc_ctx* c, uint32_t max_n) {
@@ -242,7 +243,7 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
       c->stats.launches_outside++;
     }
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 2], st));
-    launch_finalize(b, nseq, gmax, st);
+    launch_finalize(b, nseq, gmax, dmin_out, st);
     c->stats.launches_other++;
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 3], st));
     HIPCHK(hipGetLastError());

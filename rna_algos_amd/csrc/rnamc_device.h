@@ -29,7 +29,8 @@ void launch_inside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n
                    uint32_t block, bool do_sums, bool do_pair, hipStream_t st);
 void launch_outside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
                     uint32_t block, hipStream_t st);
-void launch_finalize(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st);
+void launch_finalize(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, uint32_t dmin_out,
+                     hipStream_t st);
 
 }  // namespace rnamc
 

@@ -31,7 +31,8 @@ enum Mat : int {
   M_QM = 7,   // sums_multibranch                    diag-major (inside pass)
   M_PM2 = 7,  // probs_multibranch2                  row-major  (outside pass, same slot)
   M_W = 8,    // (P + mbclose) - Qb of a pair        diag-major (outside pass)
-  M_ZRM = 9,  // sums_rightmost_basepairs_multibranch diag-major (CONTRAfold only)
+  M_ZRM = 9,  // sums_rightmost_basepairs_multibranch diag-major (CONTRAfold, inside pass)
+  M_P = 9,    // log basepair_probs                  diag-major (outside pass, same slot)
   M_COUNT = 10
 };
 

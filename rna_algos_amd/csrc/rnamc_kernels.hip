@@ -439,10 +439,6 @@ __global__ void k_init(DeviceBatch b) {
     const size_t mat = x / tri;
     base[x] = (mat == M_Z) ? 0.f : kNegInf;
   }
-  float* out = b.out + sd.out_off;
-  const size_t olen = static_cast<size_t>(sd.n) * (sd.n + 1u) / 2u;
-  for (size_t x = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; x < olen; x += stride)
-    out[x] = kNegInf;
   // 2-bit packed copy of the sequence: base p at bit 2(p+32); zeros around it
   uint32_t* pk = reinterpret_cast<uint32_t*>(b.workspace + sd.pk_off);
   const uint8_t* s = b.bases + sd.seq_off;
@@ -686,7 +682,11 @@ __global__ void __launch_bounds__(256) k_inside(DeviceBatch b, uint32_t d, uint3
 // outside pass (src/mccaskill_algo.rs:537-605 Turner, 638-718 CONTRAfold).
 // basepair_probs stays in the log domain in `out` until k_finalize.
 
-// probs_multibranch / probs_multibranch2 of one cell: k = j + t over pairs (i,k)
+// probs_multibranch / probs_multibranch2 of one cell: k = j + t over pairs (i,k).
+// Loads are unconditional (a lane past its own row end reads a neighbouring
+// diagonal: in bounds thanks to the 64-float pad of every matrix) and the lane's
+// validity is applied to the value, so the loop body has no exec-mask branches and
+// the 2 x 8 loads of a chunk issue back to back.
 template <bool CONTRA>
 __device__ __forceinline__ void outside_mb_cell(const DeviceBatch& b, const Seq& q, uint32_t d,
                                                 uint32_t i, bool valid, uint32_t cnt_wave,
@@ -697,8 +697,12 @@ __device__ __forceinline__ void outside_mb_cell(const DeviceBatch& b, const Seq&
   const float* __restrict__ w = q.m[M_W];
   const float mun = CONTRA ? b.params->contra.multibranch_score_unpair : 0.f;
   const uint32_t cnt = valid ? n - 1 - j : 0u;  // this lane's trip count
+  const uint32_t i4 = i * 4u;
   float pm = kNegInf, pm2 = kNegInf;
+  // W(i,k): diagonal d+t, offset i (-inf when (i,k) is no pair);
+  // sums_1ormore_basepairs[j+1][k-1]: diagonal t-2, offset j+1
   auto step = [&](float x, float r, uint32_t t) {
+    x = (t <= cnt) ? x : kNegInf;  // past this lane's row end
     pm = lse(pm, x + r, tab);
     if (CONTRA) {
       pm2 = lse(pm2, x + mun * static_cast<float>(t - 1), tab);
@@ -706,22 +710,27 @@ __device__ __forceinline__ void outside_mb_cell(const DeviceBatch& b, const Seq&
       pm2 = lse(pm2, x, tab);
     }
   };
-  // W(i,k): diagonal d+t, offset i (-inf when (i,k) is no pair);
-  // sums_1ormore_basepairs[j+1][k-1]: diagonal t-2, offset j+1 (t == 1: empty interval)
-  const uint32_t i4 = i * 4u;
-  auto ld_w = [&](uint32_t t) { return (t <= cnt) ? ldu(w + tri_off(n, d + t), i4) : kNegInf; };
-  auto ld_r = [&](uint32_t t) {
-    return (t >= 2 && t <= cnt) ? ldu(q1d + tri_off(n, t - 2) + d + 1, i4) : kNegInf;
-  };
-  uint32_t t = 1;
-  if (cnt_wave >= kU) {
-    float xs[kU], rs[kU];
-#pragma unroll
-    for (int u = 0; u < kU; u++) {
-      xs[u] = ld_w(t + u);
-      rs[u] = ld_r(t + u);
+  if (cnt_wave >= 1) {
+    // t = 1: sums_1ormore_basepairs[j+1][j] is the empty interval (-inf): only pm2 moves
+    const float x1 = (1u <= cnt) ? ldu(w + tri_off(n, d + 1), i4) : kNegInf;
+    if (CONTRA) {
+      pm2 = lse(pm2, x1 + mun * 0.f, tab);
+    } else {
+      pm2 = lse(pm2, x1, tab);
     }
-    while (t + kU <= cnt_wave + 1) {
+  }
+  uint32_t t = 2;
+  if (cnt_wave >= kU + 1) {
+    float xs[kU], rs[kU];
+    auto fetch = [&](uint32_t t0) {
+#pragma unroll
+      for (int u = 0; u < kU; u++) {
+        xs[u] = ldu(w + tri_off(n, d + t0 + u), i4);
+        rs[u] = ldu(q1d + tri_off(n, t0 + u - 2) + d + 1, i4);
+      }
+    };
+    fetch(t);
+    while (t + kU <= cnt_wave + 1) {  // steps t .. t+kU-1 are all <= cnt_wave
       float xs2[kU], rs2[kU];
 #pragma unroll
       for (int u = 0; u < kU; u++) {
@@ -729,19 +738,14 @@ __device__ __forceinline__ void outside_mb_cell(const DeviceBatch& b, const Seq&
         rs2[u] = rs[u];
       }
       const uint32_t tn = t + kU;
-      if (tn + kU <= cnt_wave + 1) {
-#pragma unroll
-        for (int u = 0; u < kU; u++) {
-          xs[u] = ld_w(tn + u);
-          rs[u] = ld_r(tn + u);
-        }
-      }
+      if (tn + kU <= cnt_wave + 1) fetch(tn);
 #pragma unroll
       for (int u = 0; u < kU; u++) step(xs2[u], rs2[u], t + u);
       t = tn;
     }
   }
-  for (; t <= cnt_wave; t++) step(ld_w(t), ld_r(t), t);
+  for (; t <= cnt_wave; t++)
+    step(ldu(w + tri_off(n, d + t), i4), ldu(q1d + tri_off(n, t - 2) + d + 1, i4), t);
   if (valid) {
     const uint32_t orow = tri_off(n, i) + d;
     q.m[M_PM][orow] = pm;
@@ -795,13 +799,17 @@ __device__ __forceinline__ void outside_pair_cell(const DeviceBatch& b, const Se
   const float* __restrict__ pm2r = q.m[M_PM2];
   const uint32_t iend = paired ? i : 0u;
   const uint32_t i4 = i * 4u;
-  // (i-1)-(k+1) = i - (k+2) >= 0 on the taken path: fold the -(k+2) into the uniform base
-  auto ld_x = [&](uint32_t k) {
-    return (k + 2 <= iend) ? ldu(q1r + tri_off(n, k + 1) - (k + 2), i4) : kNegInf;
-  };
-  auto ld_y = [&](uint32_t k) { return (k < iend) ? ldu(pmr + tri_off(n, k) + d - k, i4) : kNegInf; };
-  auto ld_y2 = [&](uint32_t k) { return (k < iend) ? ldu(pm2r + tri_off(n, k) + d - k, i4) : kNegInf; };
+  // unconditional loads (in bounds: see outside_mb_cell), validity applied to values:
+  //   k < iend   : the step exists for this lane
+  //   k+2 <= iend: the interval [k+1, i-1] is not empty
+  auto ld_x = [&](uint32_t k) { return ldu(q1r + tri_off(n, k + 1) - (k + 2), i4); };
+  auto ld_y = [&](uint32_t k) { return ldu(pmr + tri_off(n, k) + d - k, i4); };
+  auto ld_y2 = [&](uint32_t k) { return ldu(pm2r + tri_off(n, k) + d - k, i4); };
   auto step = [&](float x, float y, float y2, uint32_t k) {
+    const bool vy = k < iend;
+    x = (k + 2 <= iend) ? x : kNegInf;
+    y = vy ? y : kNegInf;
+    y2 = vy ? y2 : kNegInf;
     p = lse(p, sa + y2 + x, tab);
     if (CONTRA) {
       p = lse(p, sa + y + mun * static_cast<float>(i - k - 1), tab);
@@ -813,12 +821,15 @@ __device__ __forceinline__ void outside_pair_cell(const DeviceBatch& b, const Se
   uint32_t k = 0;
   if (imax_wave >= kU) {
     float xs[kU], ys[kU], y2s[kU];
+    auto fetch = [&](uint32_t k0) {
 #pragma unroll
-    for (int u = 0; u < kU; u++) {
-      xs[u] = ld_x(k + u);
-      ys[u] = ld_y(k + u);
-      y2s[u] = ld_y2(k + u);
-    }
+      for (int u = 0; u < kU; u++) {
+        xs[u] = ld_x(k0 + u);
+        ys[u] = ld_y(k0 + u);
+        y2s[u] = ld_y2(k0 + u);
+      }
+    };
+    fetch(k);
     while (k + kU <= imax_wave) {
       float xs2[kU], ys2[kU], y2s2[kU];
 #pragma unroll
@@ -828,14 +839,7 @@ __device__ __forceinline__ void outside_pair_cell(const DeviceBatch& b, const Se
         y2s2[u] = y2s[u];
       }
       const uint32_t kn = k + kU;
-      if (kn + kU <= imax_wave) {
-#pragma unroll
-        for (int u = 0; u < kU; u++) {
-          xs[u] = ld_x(kn + u);
-          ys[u] = ld_y(kn + u);
-          y2s[u] = ld_y2(kn + u);
-        }
-      }
+      if (kn + kU <= imax_wave) fetch(kn);
 #pragma unroll
       for (int u = 0; u < kU; u++) step(xs2[u], ys2[u], y2s2[u], k + u);
       k = kn;
@@ -843,7 +847,7 @@ __device__ __forceinline__ void outside_pair_cell(const DeviceBatch& b, const Se
   }
   for (; k < imax_wave; k++) step(ld_x(k), ld_y(k), ld_y2(k), k);
   if (paired && p > kNegInf) {
-    q.out[od] = p;
+    q.m[M_P][od] = p;
     q.m[M_W][od] = p + q.m[M_MBC][od] - qb_ij;
   }
 }
@@ -891,19 +895,25 @@ __global__ void __launch_bounds__(256) k_outside(DeviceBatch b, uint32_t d, uint
   }
 }
 
-// final map (src/mccaskill_algo.rs:608 / 721) + log partition function
-__global__ void k_finalize(DeviceBatch b) {
+// final map (src/mccaskill_algo.rs:608 / 721) + log partition function.  A pair is
+// in the reference's SparseProbMat iff it got a probability, i.e. iff it is in
+// sums_close and its span was visited by the outside sweep (602-604 / 715-717).
+__global__ void k_finalize(DeviceBatch b, uint32_t dmin_out) {
   const SeqDesc sd = b.seqs[blockIdx.y];
   float* out = b.out + sd.out_off;
+  const float* base = b.workspace + sd.ws_off;
+  const float* lp = base + static_cast<size_t>(M_P) * sd.tri_pad;
+  const float* qb = base + static_cast<size_t>(M_QB) * sd.tri_pad;
   const size_t olen = static_cast<size_t>(sd.n) * (sd.n + 1u) / 2u;
+  const size_t first = tri_off(sd.n, min(dmin_out, sd.n));  // cells of shorter spans
   const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
   for (size_t x = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; x < olen;
        x += stride) {
-    const float lp = out[x];
-    out[x] = (lp > kNegInf) ? expf_ref(lp) : -1.0f;
+    const bool present = x >= first && qb[x] > kNegInf;
+    out[x] = present ? expf_ref(lp[x]) : -1.0f;
   }
   if (b.log_partition && blockIdx.x == 0 && threadIdx.x == 0) {
-    const float* z = b.workspace + sd.ws_off + static_cast<size_t>(M_Z) * sd.tri_pad;
+    const float* z = base + static_cast<size_t>(M_Z) * sd.tri_pad;
     b.log_partition[sd.batch_idx] = z[tri_off(sd.n, sd.n - 1)];
   }
 }
@@ -951,11 +961,12 @@ void launch_outside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_
   }
 }
 
-void launch_finalize(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st) {
+void launch_finalize(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, uint32_t dmin_out,
+                     hipStream_t st) {
   const uint64_t elems = static_cast<uint64_t>(max_n) * (max_n + 1) / 2;
   uint32_t gx = static_cast<uint32_t>(std::min<uint64_t>((elems + 1023) / 1024, 256));
   if (gx == 0) gx = 1;
-  hipLaunchKernelGGL(k_finalize, dim3(gx, nseq, 1), dim3(256), 0, st, b);
+  hipLaunchKernelGGL(k_finalize, dim3(gx, nseq, 1), dim3(256), 0, st, b, dmin_out);
 }
 
 }  // namespace rnamc

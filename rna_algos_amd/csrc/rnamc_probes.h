@@ -255,7 +255,7 @@ __device__ __forceinline__ float probe_fold(const DeviceBatch& b, const Seq& q, 
   const uint32_t n = q.n;
   const uint32_t j = i + d;
   const float* __restrict__ qb = q.m[M_QB];
-  const float* __restrict__ lp = q.out;
+  const float* __restrict__ lp = q.m[M_P];
   const uint32_t i4 = i * 4u;
   // windows: wa walks with a (the k side), wb walks with b (the l side)
   //  inside : wa = bases i .. i+31 (k-1 at position a, k at a+1)
@@ -311,11 +311,9 @@ __device__ __forceinline__ float probe_fold(const DeviceBatch& b, const Seq& q, 
 
   // operand addresses: pair (k,l)
   //  inside : diagonal d-2-a-bb, offset i+1+a      outside: diagonal d+2+a+bb, offset i-1-a
-  auto ok = [&](uint32_t a, uint32_t bb) {
-    bool v = act && a + bb <= lim;
-    if (OUTSIDE) v = v && a < i && j + 2 + bb <= n;
-    return v;
-  };
+  // Loads are unconditional: a probe past the row's end re-reads the row's last
+  // probe (uniform clamp), a lane whose (k,l) falls off the sequence reads a
+  // neighbouring diagonal (in bounds: 64-float pad) and is masked by value below.
   auto ubase = [&](const float* m, uint32_t a, uint32_t bb) {
     return OUTSIDE ? m + tri_off(n, d + 2 + a + bb) - 1 - a : m + tri_off(n, d - 2 - a - bb) + 1 + a;
   };
@@ -329,13 +327,17 @@ __device__ __forceinline__ float probe_fold(const DeviceBatch& b, const Seq& q, 
   };
   float xs[kPU], ps[kPU];
   auto fetch = [&](uint32_t ra, uint32_t rb) {
+    const uint32_t blast = lim - ra;  // last probe of the row
 #pragma unroll
     for (int u = 0; u < kPU; u++) {
-      const bool v = ok(ra, rb + u);
-      xs[u] = v ? ldu(ubase(qb, ra, rb + u), i4) : kNegInf;
-      if (OUTSIDE) ps[u] = v ? ldu(ubase(lp, ra, rb + u), i4) : kNegInf;
+      const uint32_t bb = min(rb + static_cast<uint32_t>(u), blast);
+      xs[u] = ldu(ubase(qb, ra, bb), i4);
+      if (OUTSIDE) ps[u] = ldu(ubase(lp, ra, bb), i4);
     }
   };
+  // outside: lane-level validity of (k,l): k = i-1-a >= 0 and l = j+1+bb <= n-1
+  const uint32_t bmax = (OUTSIDE && act && j + 2 <= n) ? n - 2 - j : 0u;  // largest valid bb
+  const bool lane_l_ok = act && (!OUTSIDE || j + 2 <= n);
   uint32_t fa = 0, fb = 0;  // fetch cursor
   fetch(fa, fb);
   chunk_next(fa, fb);
@@ -359,6 +361,7 @@ __device__ __forceinline__ float probe_fold(const DeviceBatch& b, const Seq& q, 
     const float rtm = (a == 0) ? 0.f : (a == 1 ? fx.tm0 : fx.tm2);
     uint64_t wcur = wb64;
     const uint32_t rowlen = lim - a + 1;
+    const bool row_ok = lane_l_ok && (!OUTSIDE || a < i);
     for (uint32_t b0 = 0; b0 < rowlen; b0 += kPU) {
       float cx[kPU], cp[kPU];
 #pragma unroll
@@ -411,9 +414,10 @@ __device__ __forceinline__ float probe_fold(const DeviceBatch& b, const Seq& q, 
           if (!OUTSIDE) {
             sum = lse(sum, cx[u] + y, tab);
           } else {
-            // absent pair / lane out of range: both operands are -inf; keep NaN out
+            // absent pair (sums_close = -inf) or (k,l) off the sequence: no term
             const float term = cp[u] + qb_ij - cx[u] + y;
-            sum = lse(sum, (cx[u] > kNegInf) ? term : kNegInf, tab);
+            const bool hit = row_ok && bb <= bmax && cx[u] > kNegInf;
+            sum = lse(sum, hit ? term : kNegInf, tab);
           }
         }
       }

@@ -1,34 +1,37 @@
-# PMC counter passes (separate runs, no tracing domains) over a small batch.
-# usage: bash scripts/prof_pmc.sh <workload args for quick_timing.py>
+# PMC counter passes (separate runs, no tracing domains), aggregated per kernel.
+# usage: bash scripts/prof_pmc.sh <quick_timing workload>
 set -e
 cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc
+W="${1:-top256}"
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$W
 rm -rf $OUT && mkdir -p $OUT
-W="${@:-batch128}"
 export CONTRA=0 GSIZES=1024
 i=0
 for SET in \
- "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
- "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM" \
+ "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+ "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA" \
  "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE" \
+ "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum" \
  "FETCH_SIZE" \
  "WRITE_SIZE" ; do
   i=$((i+1))
   rocprofv3 --pmc $SET --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/scripts/quick_timing.py $W > $OUT/run$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/run$i.log; }
 done
-python3 - <<'PY'
+grep -h "rep0" $OUT/run1.log
+python3 - <<PY
 import csv, glob, os, collections
-out = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/pmc"
+out = "$OUT"
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
-cnt = collections.defaultdict(int)
 for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][-40:]
+        kn = r["Kernel_Name"]
+        k = "k_outside" if "k_outside" in kn else "k_inside" if "k_inside" in kn else "other"
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-for k, v in agg.items():
-    print(k)
-    for c, x in sorted(v.items()):
-        print(f"   {c:28s} {x:.4g}")
+with open(out + "/summary.txt", "w") as fh:
+    for k, v in agg.items():
+        print(k); fh.write(k + "\n")
+        for c, x in sorted(v.items()):
+            line = f"   {c:32s} {x:.5g}"
+            print(line); fh.write(line + "\n")
 PY
-# keep only the summary + small logs (the per-dispatch CSVs are large)
-find $OUT -name "*counter_collection.csv" -size +8M -delete
+find $OUT -name "*counter_collection.csv" -delete
