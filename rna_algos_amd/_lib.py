@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librnamc.so")
+LIB_PATH = os.environ.get("RNAMC_LIB") or os.path.join(_HERE, "librnamc.so")
 
 OK = 0
 ERR_INVALID_ARG, ERR_INVALID_BASE, ERR_EMPTY_SEQ, ERR_SEQ_TOO_LONG = 1, 2, 3, 4

@@ -47,6 +47,7 @@ struct rnamc_ctx {
   int64_t group_ws_bytes = 64ll << 30;
   int64_t block_threads = 256;
   int64_t profile = 0;
+  int64_t debug_roles = 15;  // timing experiments only: bit0 folds, 1 pair block, 2 mb, 3 pair probs
   // bookkeeping of the last call
   rnamc_batch_stats stats{};
   std::vector<SeqDesc> descs;       // all groups, group-major
@@ -217,6 +218,7 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
     b.params = c->d_params;
     b.hp_init = c->d_hp_init;
     b.allows_short_hairpins = allows_short ? 1 : 0;
+    b.debug = static_cast<int>(c->debug_roles);
     // sequences with n > d form a prefix of the group
     auto active = [&](uint32_t d) {
       uint32_t lo = 0, hi = nseq;  // first index with n <= d
@@ -230,16 +232,22 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
     launch_init(b, nseq, gmax, st);
     c->stats.launches_other++;
     if (dmin_in > 0 && dmin_in < gmax) {  // closing-pair block of the first diagonal
-      launch_inside(b, contra, dmin_in - 1, gmax, active(dmin_in), block, false, true, st);
+      launch_inside(b, contra, dmin_in - 1, gmax, active(dmin_in), block, false,
+                    (c->debug_roles & 2) != 0, st);
       c->stats.launches_inside++;
     }
     for (uint32_t d = dmin_in; d < gmax; d++) {
-      launch_inside(b, contra, d, gmax, active(d), block, true, d + 1 < gmax, st);
+      launch_inside(b, contra, d, gmax, active(d), block, (c->debug_roles & 1) != 0,
+                    d + 1 < gmax && (c->debug_roles & 2) != 0, st);
       c->stats.launches_inside++;
     }
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 1], st));
-    for (uint32_t d = gmax; d-- > dmin_out;) {
-      launch_outside(b, contra, d, gmax, active(d), block, st);
+    // launch d carries the 2-loop half of diagonal d-1: start one diagonal early
+    for (uint32_t d = gmax + 1; d-- > dmin_out;) {
+      const bool head = d >= 1 && d - 1 >= dmin_out;
+      launch_outside(b, contra, d, gmax, active(d >= 1 ? d - 1 : 0), block,
+                     (c->debug_roles & 4) != 0, (c->debug_roles & 8) != 0,
+                     head && (c->debug_roles & 8) != 0, st);
       c->stats.launches_outside++;
     }
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 2], st));
@@ -344,6 +352,8 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     c->block_threads = value;
   } else if (k == "profile") {
     c->profile = value;
+  } else if (k == "debug_roles") {
+    c->debug_roles = value;
   } else {
     return RNAMC_ERR_INVALID_ARG;
   }

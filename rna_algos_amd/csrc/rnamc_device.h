@@ -21,6 +21,7 @@ struct DeviceBatch {
   const rnamc_params* params;
   const float* hp_init;     // Turner hairpin initiation by loop length (host-built)
   int allows_short_hairpins;
+  int debug;  // timing experiments only (rnamc_ctx_set "debug_roles" bits 4+)
 };
 
 void launch_init(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st);
@@ -28,7 +29,7 @@ void launch_init(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, hipStream_
 void launch_inside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
                    uint32_t block, bool do_sums, bool do_pair, hipStream_t st);
 void launch_outside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
-                    uint32_t block, hipStream_t st);
+                    uint32_t block, bool do_mb, bool do_tail, bool do_head, hipStream_t st);
 void launch_finalize(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, uint32_t dmin_out,
                      hipStream_t st);
 

@@ -36,7 +36,8 @@ namespace rnamc {
 namespace {
 
 constexpr float kNegInf = -__builtin_inff();
-constexpr int kU = 8;  // k-steps fetched ahead per lane
+constexpr int kU = RNAMC_KU;  // k-steps fetched ahead per lane
+constexpr int kUE = RNAMC_KUE;  // same, multibranch half of the pair probabilities
 
 // ----------------------------------------------------------------------------
 // numerics: src/utils.rs:579-655
@@ -163,6 +164,32 @@ __device__ __forceinline__ float expf_ref(float x) {
 // SGPRs + the lane's 32-bit byte offset) instead of a 64-bit VALU address per load
 __device__ __forceinline__ float ldu(const float* __restrict__ ubase, uint32_t lane_byte_off) {
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ubase) + lane_byte_off);
+}
+
+// Two-stage software pipeline over `nchunks` whole chunks of kU steps starting at t:
+// fetch(buf, t) loads the operands of steps t..t+kU-1 into a register buffer,
+// compute(buf, t) folds them.  The loads of chunk c+1 are issued before chunk c is
+// folded and land in the OTHER buffer, so their latency hides under ~kU fold steps.
+template <class Buf, int U = kU, class Fetch, class Compute>
+__device__ __forceinline__ uint32_t pingpong(uint32_t t, uint32_t nchunks, Fetch&& fetch,
+                                             Compute&& compute) {
+  if (nchunks == 0) return t;
+  Buf A, B;
+  fetch(A, t);
+  uint32_t c = 0;
+  for (;;) {
+    if (c + 1 < nchunks) fetch(B, t + U);
+    compute(A, t);
+    t += U;
+    c++;
+    if (c >= nchunks) break;
+    if (c + 1 < nchunks) fetch(A, t + U);
+    compute(B, t);
+    t += U;
+    c++;
+    if (c >= nchunks) break;
+  }
+  return t;
 }
 
 __device__ __forceinline__ uint32_t tri_off(uint32_t n, uint32_t d) {
@@ -553,18 +580,23 @@ __device__ __forceinline__ void inside_sums_cell(const DeviceBatch& b, const Seq
     zr_ext = kNegInf;
     zr_mb = kNegInf;
     // k = i + t, j - k = d - t; sums_accessible(i,k) is -inf when (i,k) is no pair
-    uint32_t t = 1;
-    for (; t + kU <= d + 1; t += kU) {
+    struct ABuf {
       float xs[kU];
+    };
+    uint32_t t = pingpong<ABuf>(
+        1u, d / kU,
+        [&](ABuf& B, uint32_t t0) {
 #pragma unroll
-      for (int u = 0; u < kU; u++) xs[u] = ldu(qa + tri_off(n, t + u), i * 4u);
+          for (int u = 0; u < kU; u++) B.xs[u] = ldu(qa + tri_off(n, t0 + u), i * 4u);
+        },
+        [&](const ABuf& B, uint32_t t0) {
 #pragma unroll
-      for (int u = 0; u < kU; u++) {
-        const float cnt = static_cast<float>(d - t - u);
-        zr_ext = lse(zr_ext, xs[u] + ebp + eun * cnt, tab);
-        zr_mb = lse(zr_mb, xs[u] + mbp + mun * cnt, tab);
-      }
-    }
+          for (int u = 0; u < kU; u++) {
+            const float cnt = static_cast<float>(d - t0 - u);
+            zr_ext = lse(zr_ext, B.xs[u] + ebp + eun * cnt, tab);
+            zr_mb = lse(zr_mb, B.xs[u] + mbp + mun * cnt, tab);
+          }
+        });
     for (; t <= d; t++) {
       const float x = qa[tri_off(n, t) + i];
       const float cnt = static_cast<float>(d - t);
@@ -597,38 +629,28 @@ __device__ __forceinline__ void inside_sums_cell(const DeviceBatch& b, const Seq
       s2 = lse(s2, qq + rm, tab);
     }
   };
-  uint32_t t = 1;
   const uint32_t i4 = i * 4u;
-  if (d > kU) {
+  struct SBuf {
     float re[kU], rm[kU], zz[kU], qq[kU];
-    auto fetch = [&](uint32_t t0) {
+  };
+  // steps 1 .. d-1
+  uint32_t t = pingpong<SBuf>(
+      1u, d >= 1 ? (d - 1) / kU : 0u,
+      [&](SBuf& B, uint32_t t0) {
 #pragma unroll
-      for (int u = 0; u < kU; u++) {
-        const uint32_t orr = tri_off(n, d - t0 - u) + t0 + u;
-        const uint32_t o = tri_off(n, t0 + u - 1);
-        re[u] = ldu(zre + orr, i4);
-        if (CONTRA) rm[u] = ldu(zrm + orr, i4);
-        zz[u] = ldu(z + o, i4);
-        qq[u] = ldu(q1 + o, i4);
-      }
-    };
-    fetch(t);
-    while (t + kU <= d) {  // steps t .. t+kU-1 are all < d
-      float re2[kU], rm2[kU], zz2[kU], qq2[kU];
+        for (int u = 0; u < kU; u++) {
+          const uint32_t orr = tri_off(n, d - t0 - u) + t0 + u;
+          const uint32_t o = tri_off(n, t0 + u - 1);
+          B.re[u] = ldu(zre + orr, i4);
+          B.rm[u] = CONTRA ? ldu(zrm + orr, i4) : 0.f;
+          B.zz[u] = ldu(z + o, i4);
+          B.qq[u] = ldu(q1 + o, i4);
+        }
+      },
+      [&](const SBuf& B, uint32_t t0) {
 #pragma unroll
-      for (int u = 0; u < kU; u++) {
-        re2[u] = re[u];
-        rm2[u] = CONTRA ? rm[u] : 0.f;
-        zz2[u] = zz[u];
-        qq2[u] = qq[u];
-      }
-      const uint32_t tn = t + kU;
-      if (tn + kU <= d) fetch(tn);  // uniform
-#pragma unroll
-      for (int u = 0; u < kU; u++) step(re2[u], rm2[u], zz2[u], qq2[u], t + u);
-      t = tn;
-    }
-  }
+        for (int u = 0; u < kU; u++) step(B.re[u], B.rm[u], B.zz[u], B.qq[u], t0 + u);
+      });
   for (; t < d; t++) {
     const uint32_t orr = tri_off(n, d - t) + t + i;
     const uint32_t o = tri_off(n, t - 1) + i;
@@ -719,31 +741,23 @@ __device__ __forceinline__ void outside_mb_cell(const DeviceBatch& b, const Seq&
       pm2 = lse(pm2, x1, tab);
     }
   }
-  uint32_t t = 2;
-  if (cnt_wave >= kU + 1) {
+  struct DBuf {
     float xs[kU], rs[kU];
-    auto fetch = [&](uint32_t t0) {
+  };
+  // steps 2 .. cnt_wave
+  uint32_t t = pingpong<DBuf>(
+      2u, cnt_wave >= 2 ? (cnt_wave - 1) / kU : 0u,
+      [&](DBuf& B, uint32_t t0) {
 #pragma unroll
-      for (int u = 0; u < kU; u++) {
-        xs[u] = ldu(w + tri_off(n, d + t0 + u), i4);
-        rs[u] = ldu(q1d + tri_off(n, t0 + u - 2) + d + 1, i4);
-      }
-    };
-    fetch(t);
-    while (t + kU <= cnt_wave + 1) {  // steps t .. t+kU-1 are all <= cnt_wave
-      float xs2[kU], rs2[kU];
+        for (int u = 0; u < kU; u++) {
+          B.xs[u] = ldu(w + tri_off(n, d + t0 + u), i4);
+          B.rs[u] = ldu(q1d + tri_off(n, t0 + u - 2) + d + 1, i4);
+        }
+      },
+      [&](const DBuf& B, uint32_t t0) {
 #pragma unroll
-      for (int u = 0; u < kU; u++) {
-        xs2[u] = xs[u];
-        rs2[u] = rs[u];
-      }
-      const uint32_t tn = t + kU;
-      if (tn + kU <= cnt_wave + 1) fetch(tn);
-#pragma unroll
-      for (int u = 0; u < kU; u++) step(xs2[u], rs2[u], t + u);
-      t = tn;
-    }
-  }
+        for (int u = 0; u < kU; u++) step(B.xs[u], B.rs[u], t0 + u);
+      });
   for (; t <= cnt_wave; t++)
     step(ldu(w + tri_off(n, d + t), i4), ldu(q1d + tri_off(n, t - 2) + d + 1, i4), t);
   if (valid) {
@@ -753,22 +767,20 @@ __device__ __forceinline__ void outside_mb_cell(const DeviceBatch& b, const Seq&
   }
 }
 
-// pair probability of one cell: exterior term ⊕ enclosing 2-loops ⊕ multibranch
-// contexts (559-605 / 663-718)
+// pair probability of one cell, first half: exterior term ⊕ enclosing 2-loops
+// (559-593 / 663-700).  Needs only results of spans >= span+2, so it runs one
+// launch ahead of the second half and parks the running sum in the log-prob slot.
 template <bool CONTRA>
-__device__ __forceinline__ void outside_pair_cell(const DeviceBatch& b, const Seq& q, uint32_t d,
-                                                  uint32_t i, bool valid, uint32_t imax_wave,
-                                                  const LseTab* tab, const ProbeTabs& L) {
+__device__ __forceinline__ void outside_pair_head(const DeviceBatch& b, const Seq& q, uint32_t d,
+                                                  uint32_t i, bool valid, const LseTab* tab,
+                                                  const ProbeTabs& L) {
   const uint32_t n = q.n;
   const uint32_t j = i + d;
   const uint32_t od = tri_off(n, d) + i;
   const float qb_ij = valid ? q.m[M_QB][od] : kNegInf;
   const bool paired = qb_ij > kNegInf;
-  // wave-uniform early out
-  if (__ballot(paired) == 0ull) return;
+  if (__ballot(paired) == 0ull) return;  // wave-uniform
   float p = kNegInf;
-  float sa = kNegInf;
-  float mun = 0.f;
   if (paired) {
     const float qa_ij = q.m[M_QA][od];
     const float* z = q.m[M_Z];
@@ -777,23 +789,44 @@ __device__ __forceinline__ void outside_pair_cell(const DeviceBatch& b, const Se
     const float zr = (j > n - 2) ? 0.f : z[tri_off(n, n - 2 - j) + j + 1];  // Z[j+1][n-1]
     if (CONTRA) {
       p = zl + zr + qa_ij + b.params->contra.external_score_basepair - ztot;
-      sa = qa_ij + b.params->contra.multibranch_score_basepair;
     } else {
       p = zl + qa_ij + zr - ztot;
-      sa = qa_ij + b.params->turner.coeff_num_branches;
     }
   }
   // enclosing pairs (k,l) = (i-1-a, j+1+bb), a ascending (k descending), bb ascending,
   // a + bb <= 30, k >= 0, l <= n-1; rows with d+2+a > n-1 have no diagonal left
-  if (d + 2 < n) {
+  if (d + 2 < n && !(b.debug & 16)) {
     const uint32_t lim = min(static_cast<uint32_t>(RNAMC_MAX_2LOOP_LEN), n - 3 - d);
     p = probe_fold<CONTRA, true>(b, q, d, i, paired, lim, p, qb_ij, tab, L);
   }
+  if (paired) q.m[M_P][od] = p;
+}
+
+// pair probability of one cell, second half: the multibranch contexts k = 0..i-1
+// (594-605 / 701-718), continuing the fold parked by outside_pair_head:
+//   x  = sums_1ormore_basepairs[k+1][i-1]  row-major row k+1 (empty when k+1 > i-1)
+//   y2 = probs_multibranch2[k][j], y = probs_multibranch[k][j]   row-major row k
+// A lane that is no pair, or is past its own i, folds -inf terms (no-ops).
+template <bool CONTRA>
+__device__ __forceinline__ void outside_pair_tail(const DeviceBatch& b, const Seq& q, uint32_t d,
+                                                  uint32_t i, bool valid, uint32_t imax_wave,
+                                                  const LseTab* tab) {
+  const uint32_t n = q.n;
+  const uint32_t od = tri_off(n, d) + i;
+  const float qb_ij = valid ? q.m[M_QB][od] : kNegInf;
+  const bool paired = qb_ij > kNegInf;
+  if (__ballot(paired) == 0ull) return;  // wave-uniform
+  float p = kNegInf, sa = kNegInf, mun = 0.f;
+  if (paired) {
+    p = q.m[M_P][od];
+    const float qa_ij = q.m[M_QA][od];
+    if (CONTRA) {
+      sa = qa_ij + b.params->contra.multibranch_score_basepair;
+    } else {
+      sa = qa_ij + b.params->turner.coeff_num_branches;
+    }
+  }
   if (CONTRA) mun = b.params->contra.multibranch_score_unpair;
-  // multibranch contexts, k = 0..i-1 (594-601 / 701-714):
-  //   x  = sums_1ormore_basepairs[k+1][i-1]  row-major row k+1 (empty when k+1 > i-1)
-  //   y2 = probs_multibranch2[k][j], y = probs_multibranch[k][j]   row-major row k
-  // a lane that is no pair, or is past its own i, folds -inf terms (no-ops).
   const float* __restrict__ q1r = q.m[M_Q1R];
   const float* __restrict__ pmr = q.m[M_PM];
   const float* __restrict__ pm2r = q.m[M_PM2];
@@ -818,33 +851,25 @@ __device__ __forceinline__ void outside_pair_cell(const DeviceBatch& b, const Se
     }
     p = lse(p, sa + x + y, tab);
   };
-  uint32_t k = 0;
-  if (imax_wave >= kU) {
-    float xs[kU], ys[kU], y2s[kU];
-    auto fetch = [&](uint32_t k0) {
+  struct EBuf {
+    float xs[kUE], ys[kUE], y2s[kUE];
+  };
+  // steps 0 .. imax_wave-1
+  if (b.debug & 32) imax_wave = 0;
+  uint32_t k = pingpong<EBuf, kUE>(
+      0u, imax_wave / kUE,
+      [&](EBuf& B, uint32_t k0) {
 #pragma unroll
-      for (int u = 0; u < kU; u++) {
-        xs[u] = ld_x(k0 + u);
-        ys[u] = ld_y(k0 + u);
-        y2s[u] = ld_y2(k0 + u);
-      }
-    };
-    fetch(k);
-    while (k + kU <= imax_wave) {
-      float xs2[kU], ys2[kU], y2s2[kU];
+        for (int u = 0; u < kUE; u++) {
+          B.xs[u] = ld_x(k0 + u);
+          B.ys[u] = ld_y(k0 + u);
+          B.y2s[u] = ld_y2(k0 + u);
+        }
+      },
+      [&](const EBuf& B, uint32_t k0) {
 #pragma unroll
-      for (int u = 0; u < kU; u++) {
-        xs2[u] = xs[u];
-        ys2[u] = ys[u];
-        y2s2[u] = y2s[u];
-      }
-      const uint32_t kn = k + kU;
-      if (kn + kU <= imax_wave) fetch(kn);
-#pragma unroll
-      for (int u = 0; u < kU; u++) step(xs2[u], ys2[u], y2s2[u], k + u);
-      k = kn;
-    }
-  }
+        for (int u = 0; u < kUE; u++) step(B.xs[u], B.ys[u], B.y2s[u], k0 + u);
+      });
   for (; k < imax_wave; k++) step(ld_x(k), ld_y(k), ld_y2(k), k);
   if (paired && p > kNegInf) {
     q.m[M_P][od] = p;
@@ -852,12 +877,14 @@ __device__ __forceinline__ void outside_pair_cell(const DeviceBatch& b, const Se
   }
 }
 
-// One launch of the outside sweep on diagonal d: blocks [0, blocks_mb) fold
-// probs_multibranch{,2}, the rest compute the pair probabilities.  Both read
-// only results of longer spans, so they are independent within the launch.
+// One launch of the outside sweep: three independent roles in disjoint blocks —
+// probs_multibranch{,2} of diagonal d, the multibranch half of the pair
+// probabilities of diagonal d, and the 2-loop half of diagonal d-1 (which the
+// next launch continues).  All read only results of longer spans.
 template <bool CONTRA>
 __global__ void __launch_bounds__(256) k_outside(DeviceBatch b, uint32_t d, uint32_t blocks_mb,
-                                                 uint32_t nseq) {
+                                                 uint32_t blocks_head, uint32_t nseq, int do_mb,
+                                                 int do_tail, int do_head) {
   __shared__ LseTab tabs;
   __shared__ ProbeTabs L;
   const LseTab* tab = &tabs;
@@ -869,20 +896,20 @@ __global__ void __launch_bounds__(256) k_outside(DeviceBatch b, uint32_t d, uint
   const uint32_t which = blockIdx.x - bxr * nseq;
   const Seq q = load_seq(b, which);
   const uint32_t n = q.n;
-  if (d >= n) return;
-  const uint32_t cells = n - d;
   if (bxr < blocks_mb) {
+    if (!do_mb || d >= n) return;
+    const uint32_t cells = n - d;
     const uint32_t i = bxr * blockDim.x + threadIdx.x;
     const uint32_t wave_first = i - (threadIdx.x & 63u);  // lane 0 of this wave
     if (wave_first >= cells) return;                       // whole wave has no cell
     // the first lane of the wave has the longest walk: n-1-j with j = i+d
     const uint32_t cnt_wave = n - 1 - d - wave_first;
     outside_mb_cell<CONTRA>(b, q, d, i, i < cells, cnt_wave, tab);
-  } else {
+  } else if (bxr < 2u * blocks_mb) {
+    if (!do_tail || d >= n) return;
     const uint32_t cnt = q.ccnt[d];
     const uint32_t bx = 2u * blocks_mb - 1u - bxr;  // descending: heavy blocks first
-    if (bx * blockDim.x >= cnt) return;  // block past the list (uniform)
-    load_probe_tabs<CONTRA, true>(L, b.params);
+    if (bx * blockDim.x >= cnt) return;            // block past the list (uniform)
     const uint32_t t = bx * blockDim.x + threadIdx.x;
     const uint32_t wave_first = t - (threadIdx.x & 63u);
     if (wave_first >= cnt) return;
@@ -891,7 +918,19 @@ __global__ void __launch_bounds__(256) k_outside(DeviceBatch b, uint32_t d, uint
     // the last listed lane of the wave has the largest i, i.e. the longest walk
     const uint32_t last_lane = min(63u, cnt - 1u - wave_first);
     const uint32_t imax = static_cast<uint32_t>(__shfl(static_cast<int>(i), static_cast<int>(last_lane)));
-    outside_pair_cell<CONTRA>(b, q, d, i, valid, imax, tab, L);
+    outside_pair_tail<CONTRA>(b, q, d, i, valid, imax, tab);
+  } else {
+    if (!do_head || d == 0 || d - 1 >= n) return;
+    const uint32_t dh = d - 1;
+    const uint32_t cnt = q.ccnt[dh];
+    const uint32_t bx = bxr - 2u * blocks_mb;
+    if (bx >= blocks_head || bx * blockDim.x >= cnt) return;  // block past the list (uniform)
+    load_probe_tabs<CONTRA, true>(L, b.params);
+    const uint32_t t = bx * blockDim.x + threadIdx.x;
+    if (t - (threadIdx.x & 63u) >= cnt) return;
+    uint32_t i;
+    const bool valid = listed_cell(q, dh, t, cnt, i);
+    outside_pair_head<CONTRA>(b, q, dh, i, valid, tab, L);
   }
 }
 
@@ -949,15 +988,21 @@ void launch_inside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n
   }
 }
 
+// launch of diagonal d: probs_multibranch (do_mb) and multibranch half of the pair
+// probabilities (do_tail) of diagonal d, 2-loop half (do_head) of diagonal d-1
 void launch_outside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
-                    uint32_t block, hipStream_t st) {
-  if (d >= max_n || nseq == 0) return;
-  const uint32_t nb = (max_n - d + block - 1) / block;
-  const dim3 g(2 * nb * nseq, 1, 1);
+                    uint32_t block, bool do_mb, bool do_tail, bool do_head, hipStream_t st) {
+  if (nseq == 0) return;
+  const uint32_t nb = d < max_n ? (max_n - d + block - 1) / block : 0;
+  const uint32_t nh = (do_head && d >= 1 && d - 1 < max_n) ? (max_n - d + 1 + block - 1) / block : 0;
+  if (2 * nb + nh == 0) return;
+  const dim3 g((2 * nb + nh) * nseq, 1, 1);
   if (contra) {
-    hipLaunchKernelGGL(k_outside<true>, g, dim3(block), 0, st, b, d, nb, nseq);
+    hipLaunchKernelGGL(k_outside<true>, g, dim3(block), 0, st, b, d, nb, nh, nseq, do_mb ? 1 : 0,
+                       do_tail ? 1 : 0, do_head ? 1 : 0);
   } else {
-    hipLaunchKernelGGL(k_outside<false>, g, dim3(block), 0, st, b, d, nb, nseq);
+    hipLaunchKernelGGL(k_outside<false>, g, dim3(block), 0, st, b, d, nb, nh, nseq, do_mb ? 1 : 0,
+                       do_tail ? 1 : 0, do_head ? 1 : 0);
   }
 }
 

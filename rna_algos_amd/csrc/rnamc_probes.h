@@ -325,25 +325,25 @@ __device__ __forceinline__ float probe_fold(const DeviceBatch& b, const Seq& q, 
       rb = 0;
     }
   };
-  float xs[kPU], ps[kPU];
-  auto fetch = [&](uint32_t ra, uint32_t rb) {
+  struct PBuf {
+    float xs[kPU], ps[kPU];
+  };
+  auto fetch = [&](PBuf& B, uint32_t ra, uint32_t rb) {
     const uint32_t blast = lim - ra;  // last probe of the row
 #pragma unroll
     for (int u = 0; u < kPU; u++) {
       const uint32_t bb = min(rb + static_cast<uint32_t>(u), blast);
-      xs[u] = ldu(ubase(qb, ra, bb), i4);
-      if (OUTSIDE) ps[u] = ldu(ubase(lp, ra, bb), i4);
+      B.xs[u] = ldu(ubase(qb, ra, bb), i4);
+      B.ps[u] = OUTSIDE ? ldu(ubase(lp, ra, bb), i4) : 0.f;
     }
   };
   // outside: lane-level validity of (k,l): k = i-1-a >= 0 and l = j+1+bb <= n-1
   const uint32_t bmax = (OUTSIDE && act && j + 2 <= n) ? n - 2 - j : 0u;  // largest valid bb
   const bool lane_l_ok = act && (!OUTSIDE || j + 2 <= n);
-  uint32_t fa = 0, fb = 0;  // fetch cursor
-  fetch(fa, fb);
-  chunk_next(fa, fb);
-
   const char* gbase = reinterpret_cast<const char*>(&L.g[0][0]);
-  for (uint32_t a = 0; a <= lim; a++) {
+
+  // one chunk: probes (a, b0 .. b0+kPU-1)
+  auto do_chunk = [&](const PBuf& B, uint32_t a, uint32_t b0) {
     // row constants: 4-bit slice of the a-side window -> byte offset of r in a float2 row
     const uint32_t rs = OUTSIDE ? static_cast<uint32_t>(wa64 >> (2u * (30u - a))) & 15u
                                 : static_cast<uint32_t>(wa64 >> (2u * a)) & 15u;
@@ -359,69 +359,80 @@ __device__ __forceinline__ float probe_fold(const DeviceBatch& b, const Seq& q, 
     // class of the row's long tail (b >= 4)
     const uint32_t rcls = (a == 0) ? 3u : (a == 1 ? 0u : 2u);
     const float rtm = (a == 0) ? 0.f : (a == 1 ? fx.tm0 : fx.tm2);
-    uint64_t wcur = wb64;
+    uint64_t wcur = wb64 >> (2u * b0);
     const uint32_t rowlen = lim - a + 1;
     const bool row_ok = lane_l_ok && (!OUTSIDE || a < i);
-    for (uint32_t b0 = 0; b0 < rowlen; b0 += kPU) {
-      float cx[kPU], cp[kPU];
 #pragma unroll
-      for (int u = 0; u < kPU; u++) {
-        cx[u] = xs[u];
-        cp[u] = OUTSIDE ? ps[u] : 0.f;
-      }
-      if (fa <= lim) {
-        fetch(fa, fb);
-        chunk_next(fa, fb);
-      }
-#pragma unroll
-      for (int u = 0; u < kPU; u++) {
-        const uint32_t bb = b0 + u;
-        const uint32_t ts = static_cast<uint32_t>(wcur) & 15u;
-        wcur >>= 2;
-        if (bb < rowlen) {
-          float y;
-          if (u <= 2 && b0 == 0 && a <= 2) {
-            // the nine small loops: general path
-            if (!OUTSIDE) {
-              c.a1 = static_cast<int>(ts >> 2);
-              c.o1 = static_cast<int>(ts & 3u);
-            } else {
-              c.c1 = static_cast<int>(ts >> 2);
-              c.y1 = static_cast<int>(ts & 3u);
-              c.y2 = wbase(wr, (bb + 31u) & 31u);  // s[l-2], read only when bb >= 1
-            }
-            y = CONTRA ? contra_twoloop_general(L, c, a, bb)
-                       : turner_twoloop_general(L, b.params->turner, tk, c, a, bb);
-          } else {
-            uint32_t cls = rcls;
-            float ftm = rtm;
-            if (u <= 3 && b0 == 0 && !CONTRA) {
-              cls = loop_class(a, bb);
-              ftm = (cls == 3u) ? 0.f : (cls == 0u ? fx.tm0 : (cls == 1u ? fx.tm1 : fx.tm2));
-            }
-            const float2 gv = *reinterpret_cast<const float2*>(
-                gbase + (CONTRA ? 0u : cls * 2048u) + (ts << 7) + r8);
-            const float iiv = L.ii[a * 32u + bb];
-            if (!CONTRA) {
-              // INIT[len] + ninio + (TM(close) + TM(enclosed)) + pen(close) + pen(enclosed)
-              const float mm = OUTSIDE ? gv.x + ftm : ftm + gv.x;
-              y = OUTSIDE ? ((iiv + mm) + gv.y) + fx.pen : ((iiv + mm) + fx.pen) + gv.y;
-            } else {
-              // (len part + junction_single(close)) + junction_single(enclosed) + basepair
-              y = OUTSIDE ? ((iiv + gv.x) + fx.js) + fx.bp : ((iiv + fx.js) + gv.x) + gv.y;
-            }
-          }
+    for (int u = 0; u < kPU; u++) {
+      const uint32_t bb = b0 + u;
+      const uint32_t ts = static_cast<uint32_t>(wcur) & 15u;
+      wcur >>= 2;
+      if (bb < rowlen) {
+        float y;
+        if (u <= 2 && b0 == 0 && a <= 2) {
+          // the nine small loops: general path
           if (!OUTSIDE) {
-            sum = lse(sum, cx[u] + y, tab);
+            c.a1 = static_cast<int>(ts >> 2);
+            c.o1 = static_cast<int>(ts & 3u);
           } else {
-            // absent pair (sums_close = -inf) or (k,l) off the sequence: no term
-            const float term = cp[u] + qb_ij - cx[u] + y;
-            const bool hit = row_ok && bb <= bmax && cx[u] > kNegInf;
-            sum = lse(sum, hit ? term : kNegInf, tab);
+            c.c1 = static_cast<int>(ts >> 2);
+            c.y1 = static_cast<int>(ts & 3u);
+            c.y2 = wbase(wr, (bb + 31u) & 31u);  // s[l-2], read only when bb >= 1
           }
+          y = CONTRA ? contra_twoloop_general(L, c, a, bb)
+                     : turner_twoloop_general(L, b.params->turner, tk, c, a, bb);
+        } else {
+          uint32_t cls = rcls;
+          float ftm = rtm;
+          if (u <= 3 && b0 == 0 && !CONTRA) {
+            cls = loop_class(a, bb);
+            ftm = (cls == 3u) ? 0.f : (cls == 0u ? fx.tm0 : (cls == 1u ? fx.tm1 : fx.tm2));
+          }
+          const float2 gv = *reinterpret_cast<const float2*>(
+              gbase + (CONTRA ? 0u : cls * 2048u) + (ts << 7) + r8);
+          const float iiv = L.ii[a * 32u + bb];
+          if (!CONTRA) {
+            // INIT[len] + ninio + (TM(close) + TM(enclosed)) + pen(close) + pen(enclosed)
+            const float mm = OUTSIDE ? gv.x + ftm : ftm + gv.x;
+            y = OUTSIDE ? ((iiv + mm) + gv.y) + fx.pen : ((iiv + mm) + fx.pen) + gv.y;
+          } else {
+            // (len part + junction_single(close)) + junction_single(enclosed) + basepair
+            y = OUTSIDE ? ((iiv + gv.x) + fx.js) + fx.bp : ((iiv + fx.js) + gv.x) + gv.y;
+          }
+        }
+        if (!OUTSIDE) {
+          sum = lse(sum, B.xs[u] + y, tab);
+        } else {
+          // absent pair (sums_close = -inf) or (k,l) off the sequence: no term
+          const float term = B.ps[u] + qb_ij - B.xs[u] + y;
+          const bool hit = row_ok && bb <= bmax && B.xs[u] > kNegInf;
+          sum = lse(sum, hit ? term : kNegInf, tab);
         }
       }
     }
+  };
+
+  // two-stage pipeline over the chunk sequence (rows a ascending, chunks b0 ascending)
+  PBuf A, B;
+  uint32_t a = 0, b0 = 0;    // chunk being folded
+  uint32_t fa = 0, fb = 0;   // next chunk to fetch
+  fetch(A, fa, fb);
+  chunk_next(fa, fb);
+  for (;;) {
+    bool more = fa <= lim;
+    if (more) fetch(B, fa, fb);
+    do_chunk(A, a, b0);
+    if (!more) break;
+    a = fa;
+    b0 = fb;
+    chunk_next(fa, fb);
+    more = fa <= lim;
+    if (more) fetch(A, fa, fb);
+    do_chunk(B, a, b0);
+    if (!more) break;
+    a = fa;
+    b0 = fb;
+    chunk_next(fa, fb);
   }
   return sum;
 }

@@ -59,6 +59,10 @@ def main():
     P = FoldScoreSets.synthetic(1)
     ctx = Context(P, device=0)
     ctx.set("profile", 1)
+    if os.environ.get("ROLES"):
+        ctx.set("debug_roles", int(os.environ["ROLES"]))
+    if os.environ.get("BLOCK"):
+        ctx.set("block_threads", int(os.environ["BLOCK"]))
     what = sys.argv[1:] or ["n1024", "n4096", "batch256"]
     for w in what:
         if w == "n1024":

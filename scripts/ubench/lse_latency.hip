@@ -1,0 +1,136 @@
+// Dependent-chain latency of one logsumexp fold step on gfx950, three variants:
+//  A: cell-LUT piece lookup (2 dependent ds_reads)     B: compare ladder + 1 ds_read
+//  C: all-VALU select tree (no LDS)
+// One wave per block; occupancy varied by grid size (blocks per CU).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cmath>
+
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+constexpr float kNegInf = -__builtin_inff();
+__constant__ float kCoef[9][4] = {
+    {-0.0065591595f, 0.12764427f, 0.49965546f, 0.6931542f}, {-0.015515756f, 0.14467756f, 0.48829398f, 0.6958093f},
+    {-0.012890925f, 0.13010283f, 0.51503986f, 0.6795586f}, {-0.0072142647f, 0.087754086f, 0.6208708f, 0.5909676f},
+    {-0.0031455354f, 0.046722945f, 0.7592532f, 0.43487945f}, {-0.0010110698f, 0.018594341f, 0.88317305f, 0.25236955f},
+    {-0.000196278f, 0.0046084408f, 0.9634432f, 0.09831489f}, {-0.0000113994f, 0.0003734731f, 0.9959107f, 0.0149855051f},
+    {0.f, 0.f, 1.f, 0.f}};
+__constant__ float kBreaks[8] = {0.66153675f, 1.6320158f, 2.4912589f, 3.3792500f, 4.426169f, 5.789071f, 7.8162727f, 11.862479f};
+struct Tab { float4 coef[9]; float2 cell[42]; };
+__device__ void load_tab(Tab* t) {
+  unsigned x = threadIdx.x;
+  if (x < 9) t->coef[x] = make_float4(kCoef[x][0], kCoef[x][1], kCoef[x][2], kCoef[x][3]);
+  if (x < 42) {
+    float lo, hi;
+    if (x == 0) { lo = 0; hi = 0.5f; } else if (x == 41) { lo = 16.f; hi = __builtin_inff(); }
+    else { lo = __uint_as_float((0x3EFu + x) << 20); hi = __uint_as_float((0x3EFu + x + 1) << 20); }
+    int piece = 0; for (int k = 0; k < 8; k++) piece += lo >= kBreaks[k];
+    float thr = __builtin_inff(); if (piece < 8 && kBreaks[piece] < hi) thr = kBreaks[piece];
+    t->cell[x] = make_float2(thr, __uint_as_float(piece * 16u));
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ float lseA(float sum, float x, const Tab* tab) {
+  float hi = vmax(sum, x), lo = vmin(sum, x), z = hi - lo;
+  int e = (int)(__float_as_uint(z) >> 20);
+  int cell = min(max(e, 0x3EF), 0x418) - 0x3EF;
+  float2 ce = tab->cell[cell];
+  unsigned boff = __float_as_uint(ce.y) + ((z >= ce.x) ? 16u : 0u);
+  float4 co = *(const float4*)((const char*)tab + boff);
+  float r = ((co.x * z + co.y) * z + co.z) * z + co.w;
+  r = lo + r;
+  return lo == kNegInf ? hi : r;
+}
+__device__ __forceinline__ float lseB(float sum, float x, const Tab* tab) {
+  float hi = vmax(sum, x), lo = vmin(sum, x), z = hi - lo;
+  bool c1 = z >= 3.3792500f;
+  float tmid = c1 ? 5.789071f : 1.6320158f, tlo = c1 ? 4.426169f : 0.66153675f, thi = c1 ? 7.8162727f : 2.4912589f;
+  bool c2 = z >= tmid; float t3 = c2 ? thi : tlo; bool c3 = z >= t3;
+  unsigned boff = (c1 ? 64u : 0u) | (c2 ? 32u : 0u) | (c3 ? 16u : 0u);
+  float4 co = *(const float4*)((const char*)tab + boff);
+  float r = ((co.x * z + co.y) * z + co.z) * z + co.w;
+  r = (z >= 11.862479f) ? z : r;
+  r = lo + r;
+  return lo == kNegInf ? hi : r;
+}
+#define SEL4(c, p, q) (c ? q : p)
+__device__ __forceinline__ float lseC(float sum, float x, const Tab*) {
+  float hi = vmax(sum, x), lo = vmin(sum, x), z = hi - lo;
+  bool c1 = z >= 3.3792500f;
+  float tmid = c1 ? 5.789071f : 1.6320158f, tlo = c1 ? 4.426169f : 0.66153675f, thi = c1 ? 7.8162727f : 2.4912589f;
+  float a0 = SEL4(c1, -0.0065591595f, -0.0031455354f), a1 = SEL4(c1, -0.015515756f, -0.0010110698f), a2 = SEL4(c1, -0.012890925f, -0.000196278f), a3 = SEL4(c1, -0.0072142647f, -0.0000113994f);
+  float b0 = SEL4(c1, 0.12764427f, 0.046722945f), b1 = SEL4(c1, 0.14467756f, 0.018594341f), b2 = SEL4(c1, 0.13010283f, 0.0046084408f), b3 = SEL4(c1, 0.087754086f, 0.0003734731f);
+  float d0 = SEL4(c1, 0.49965546f, 0.7592532f), d1 = SEL4(c1, 0.48829398f, 0.88317305f), d2 = SEL4(c1, 0.51503986f, 0.9634432f), d3 = SEL4(c1, 0.6208708f, 0.9959107f);
+  float e0 = SEL4(c1, 0.6931542f, 0.43487945f), e1 = SEL4(c1, 0.6958093f, 0.25236955f), e2 = SEL4(c1, 0.6795586f, 0.09831489f), e3 = SEL4(c1, 0.5909676f, 0.0149855051f);
+  bool c2 = z >= tmid; float t3 = c2 ? thi : tlo;
+  float aa0 = c2 ? a2 : a0, aa1 = c2 ? a3 : a1, bb0 = c2 ? b2 : b0, bb1 = c2 ? b3 : b1, dd0 = c2 ? d2 : d0, dd1 = c2 ? d3 : d1, ee0 = c2 ? e2 : e0, ee1 = c2 ? e3 : e1;
+  bool c3 = z >= t3;
+  float a = c3 ? aa1 : aa0, bq = c3 ? bb1 : bb0, c = c3 ? dd1 : dd0, dq = c3 ? ee1 : ee0;
+  float r = ((a * z + bq) * z + c) * z + dq;
+  r = (z >= 11.862479f) ? z : r;
+  r = lo + r;
+  return lo == kNegInf ? hi : r;
+}
+template <int V, int CH>
+__global__ void __launch_bounds__(64) k(float* out, unsigned long long* cyc, int iters) {
+  __shared__ Tab tab;
+  load_tab(&tab);
+  float s[CH];
+  for (int c = 0; c < CH; c++) s[c] = threadIdx.x * 0.01f + c;
+  float x = 0.3f + threadIdx.x * 0.001f;
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        float xx = x + (float)(u + c) * 0.37f;
+        if (V == 0) s[c] = lseA(s[c], xx, &tab);
+        if (V == 1) s[c] = lseB(s[c], xx, &tab);
+        if (V == 2) s[c] = lseC(s[c], xx, &tab);
+      }
+    }
+    x += 0.001f;
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float r = 0; for (int c = 0; c < CH; c++) r += s[c];
+  out[blockIdx.x * 64 + threadIdx.x] = r;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+template <int V, int CH>
+void run(const char* name) {
+  float* out; unsigned long long* cyc;
+  hipMalloc(&out, 4 * 64 * 65536); hipMalloc(&cyc, 8 * 65536);
+  const int iters = 500;
+  printf("%-34s", name);
+  for (int wps : {1, 2, 4, 8}) {
+    int blocks = 1024 * wps;  // one wave per block -> wps waves per SIMD
+    hipLaunchKernelGGL((k<V, CH>), dim3(blocks), dim3(64), 0, 0, out, cyc, 10);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k<V, CH>), dim3(blocks), dim3(64), 0, 0, out, cyc, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long h[16]; hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+    double per = (double)h[3] / (iters * 8.0);   // cycles per step (CH folds) for one wave
+    double ns_per_lse_simd = ms * 1e6 / ((double)iters * 8 * CH * wps);
+    printf("  w%d: %6.0f cyc/step %5.2f ns/lse/SIMD", wps, per, ns_per_lse_simd);
+  }
+  printf("\n");
+  hipFree(out); hipFree(cyc);
+}
+int main() {
+  run<0, 1>("A cell-LUT        1 chain");
+  run<1, 1>("B ladder+LDS coef 1 chain");
+  run<2, 1>("C all-VALU        1 chain");
+  run<0, 2>("A cell-LUT        2 chains");
+  run<1, 2>("B ladder+LDS coef 2 chains");
+  run<2, 2>("C all-VALU        2 chains");
+  run<0, 3>("A cell-LUT        3 chains");
+  run<1, 3>("B ladder+LDS coef 3 chains");
+  run<2, 3>("C all-VALU        3 chains");
+  run<0, 6>("A cell-LUT        6 chains");
+  run<2, 6>("C all-VALU        6 chains");
+  return 0;
+}
