@@ -266,7 +266,7 @@ struct TwoLoopCodes {
   int a0, a1, o0, o1;          // enclosed side
 };
 
-constexpr int kPU = 8;                                   // probes fetched ahead
+constexpr int kPU = RNAMC_KPU;                          // probes fetched ahead
 constexpr uint32_t kProbes = (RNAMC_MAX_2LOOP_LEN + 1) * (RNAMC_MAX_2LOOP_LEN + 2) / 2;  // 496
 static_assert(kProbes % kPU == 0, "probe list is walked in whole chunks");
 static_assert(RNAMC_MAX_2LOOP_LEN == RNAMC_MAX_LOOP_LEN, "one probe triangle for both models");

@@ -204,3 +204,68 @@ def test_n4096_properties(ctx, params):
         off += n - d
     assert rowsum.max() < 1.0 + 5e-2
     assert np.isfinite(logz[0]) and logz[0] > 0
+
+
+def test_n4096_contra_golden(ctx, params):
+    """Full-size CONTRAfold run (n = 4096) against the oracle's committed checksum."""
+    gold_path = os.path.join(os.path.dirname(__file__), "golden", "checksums_n4096_contra.json")
+    g = json.load(open(gold_path))["cases"]["n4096_seed4096_contra"]
+    s = O.splitmix_seq(4096, 4096)
+    mats, logz = ctx.bpp_batch([s], True, False)
+    assert int(np.float32(logz[0]).view(np.uint32)) == g["log_partition_bits"]
+    a = mats[0].packed.copy()
+    assert int((a >= -0.5).sum()) == g["present"]
+    a[a >= 0.9999] = 1.0
+    assert hashlib.sha256(a.tobytes()).hexdigest() == g["sha256"]
+
+
+def test_centroid_fold_end_to_end(ctx, params, trnas):
+    """BASELINE.json configs[4]: gamma-centroid fold driven off the GPU bpp matrices of
+    assets/sampled_trnas.fa — structures identical to the CPU path (oracle bpp + oracle
+    fold) for every gamma of the reference binary's grid (src/bin/centroid_fold.rs:9-10)."""
+    from rna_algos_amd.centroid_fold import centroid_fold, get_fold_str, MIN_POW_2, MAX_POW_2
+    seqs = [s for _, s in trnas]
+    for contra in (False, True):
+        mats, _ = ctx.bpp_batch(seqs, contra, False)
+        for s, m in zip(seqs, mats):
+            ref_bpp, _ = O.bpp(params.ptr, s, contra, False)
+            for k in range(MIN_POW_2, MAX_POW_2 + 1):
+                gamma = float(2.0 ** k)
+                fold = centroid_fold(m, len(s), gamma)
+                ref_pairs, ref_acc = O.centroid_fold(ref_bpp, len(s), gamma)
+                assert fold.basepair_pos_pairs == ref_pairs
+                assert np.float32(fold.expect_accuracy) == np.float32(ref_acc)
+                assert len(get_fold_str(fold, len(s))) == len(s)
+
+
+def test_device_resident_api(params):
+    """rnamc_bpp_batch_device: inputs and outputs stay in HBM, work is enqueued on the
+    caller's stream (what bench.py times)."""
+    import torch
+    from rna_algos_amd.mccaskill_algo import Context
+    rng = np.random.default_rng(21)
+    seqs = [rng.integers(0, 4, int(n)).astype(np.uint8) for n in (77, 300, 5, 128, 511)]
+    lens = np.array([len(s) for s in seqs], dtype=np.uint64)
+    offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=offsets[1:])
+    out_offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    np.cumsum(lens * (lens + np.uint64(1)) // np.uint64(2), out=out_offsets[1:])
+    dev = torch.device("cuda:0")
+    d_bases = torch.from_numpy(np.concatenate(seqs)).to(dev)
+    d_out = torch.full((int(out_offsets[-1]),), 7.0, dtype=torch.float32, device=dev)
+    d_logz = torch.zeros(len(seqs), dtype=torch.float32, device=dev)
+    c = Context(params, device=0)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        c.bpp_batch_device(len(seqs), d_bases.data_ptr(), offsets, True, False, d_out.data_ptr(),
+                           out_offsets, d_logz.data_ptr(), side.cuda_stream)
+    side.synchronize()
+    out = d_out.cpu().numpy()
+    logz = d_logz.cpu().numpy()
+    for k, s in enumerate(seqs):
+        ref, ref_z = O.bpp(params.ptr, s, True, False)
+        assert_same(out[int(out_offsets[k]):int(out_offsets[k + 1])], ref, f"device api seq {k}")
+        assert np.float32(logz[k]) == ref_z
+    st = c.stats()
+    assert st["n_groups"] == 1 and st["launches_outside"] > 0
+    c.close()

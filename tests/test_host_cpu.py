@@ -1,0 +1,147 @@
+"""CPU suite, part 2: the C-ABI library loads and exports every symbol include/rnamc.h
+declares, host-side logic (encoding, parameter plumbing, centroid fold, sharding) works,
+and the product refuses to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    from rna_algos_amd import _lib
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "rnamc.h")).read()
+    # prototypes start a line with a return type: "int rnamc_x(", "const char* rnamc_y(" ...
+    declared = set(re.findall(r"^(?:const )?[a-z_0-9]+\*? (rnamc_[a-z0-9_]+)\(", hdr, re.M))
+    assert declared, "no prototypes found"
+    for sym in sorted(declared):
+        assert hasattr(L, sym), f"librnamc.so lacks {sym}"
+    assert set(_lib.SYMBOLS) == declared
+    assert L.rnamc_abi_version() == 2
+    assert L.rnamc_params_sizeof() > 300000
+
+
+def test_bytes2seq(built):
+    from rna_algos_amd.utils import bytes2seq
+    from rna_algos_amd import _lib
+    assert list(bytes2seq(b"ACGUacgu")) == [0, 1, 2, 3, 0, 1, 2, 3]
+    with pytest.raises(_lib.RnamcError):  # the reference panics (src/utils.rs:570-572)
+        bytes2seq(b"ACGT")
+    assert bytes2seq(b"").shape == (0,)
+
+
+def test_packed_index(built):
+    from rna_algos_amd import _lib
+    from rna_algos_amd.mccaskill_algo import bpp_index, bpp_len
+    L = _lib.lib()
+    n = 37
+    seen = set()
+    for i in range(n):
+        for j in range(i, n):
+            k = L.rnamc_bpp_index(n, i, j)
+            assert k == bpp_index(n, i, j)
+            seen.add(k)
+    assert seen == set(range(bpp_len(n))) and L.rnamc_bpp_len(n) == bpp_len(n)
+
+
+def test_fold_score_sets_plumbing(built, tmp_path):
+    from rna_algos_amd.utils import FoldScoreSets
+    src = FoldScoreSets.synthetic(7)
+    fss = FoldScoreSets.new(0.0)
+    assert float(np.abs(fss.stack_scores).max()) == 0.0
+    fss.transfer(src)
+    canon = lambda a, b: (a + b == 3) or (a + b == 5)
+    for a in range(4):
+        for b in range(4):
+            for c in range(4):
+                for d in range(4):
+                    v = fss.stack_scores[a, b, c, d]
+                    if canon(a, b) and canon(c, d):
+                        assert v != 0.0
+                    else:  # transfer() leaves non-canonical entries at init_val
+                        assert v == 0.0
+                    if not canon(a, b):
+                        assert fss.terminal_mismatch_scores[a, b, c, d] == 0.0
+    # accumulate(): running f32 sums
+    acc = np.float32(0)
+    for k in range(31):
+        acc = np.float32(acc + fss.hairpin_scores_len[k])
+        assert fss.hairpin_scores_len_cumulative[k] == acc
+    # synthetic() is deterministic and seed-sensitive
+    assert np.array_equal(FoldScoreSets.synthetic(7)._buf, src._buf)
+    assert not np.array_equal(FoldScoreSets.synthetic(8)._buf, src._buf)
+    # table file round trip
+    path = os.path.join(tmp_path, "t.bin")
+    src.save(path)
+    assert np.array_equal(FoldScoreSets.load(path)._buf, src._buf)
+    with open(path, "r+b") as fh:
+        fh.write(b"XXXX")
+    from rna_algos_amd import _lib
+    with pytest.raises(_lib.RnamcError):
+        FoldScoreSets.load(path)
+
+
+def test_no_gpu_means_no_result(built, params):
+    """The product path must fail loudly without a HIP device (this container has none)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from rna_algos_amd import _lib
+    from rna_algos_amd.mccaskill_algo import Context
+    with pytest.raises(_lib.RnamcError) as e:
+        Context(params)
+    assert e.value.status == _lib.ERR_NO_DEVICE
+
+
+def test_centroid_fold_matches_oracle(built, params, trnas):
+    """src/centroid_fold.rs:25-105 driven off bpp matrices, gamma = 2^-7 .. 2^10
+    (src/bin/centroid_fold.rs:9-10): product (C++) vs oracle (C), identical structures."""
+    from rna_algos_amd.centroid_fold import centroid_fold, get_fold_str, MIN_POW_2, MAX_POW_2
+    from rna_algos_amd.mccaskill_algo import BppMatrix
+    g = np.load(os.path.join(ROOT, "tests", "golden", "trna_bpp_synthetic_seed1.npz"))
+    nonempty = 0
+    for idx, (_, s) in enumerate(trnas):
+        n = len(s)
+        bpp = BppMatrix(n, g[f"trna{idx}_contra"])
+        for k in range(MIN_POW_2, MAX_POW_2 + 1):
+            gamma = float(2.0 ** k)
+            fold = centroid_fold(bpp, n, gamma)
+            ref_pairs, ref_acc = O.centroid_fold(bpp.packed, n, gamma)
+            assert fold.basepair_pos_pairs == ref_pairs
+            assert np.float32(fold.expect_accuracy) == np.float32(ref_acc)
+            st = get_fold_str(fold, n)
+            assert len(st) == n and st.count("(") == st.count(")") == len(ref_pairs)
+            nonempty += bool(ref_pairs)
+            # pairs are nested (no crossing) and each has a probability
+            for (i, j) in ref_pairs:
+                assert bpp[(i, j)] >= -0.5
+    assert nonempty > 20
+
+
+def test_lpt_sharding_properties():
+    import bench
+    rng = np.random.default_rng(1)
+    costs = rng.integers(256, 2049, 1000).astype(np.float64) ** 3
+    for world in (1, 2, 4, 8):
+        shards = bench.shard_lpt(costs, world)
+        allidx = np.concatenate(shards)
+        assert sorted(allidx.tolist()) == list(range(1000))
+        loads = np.array([costs[s].sum() for s in shards])
+        assert loads.max() / loads.mean() < 1.01  # LPT balance on this distribution
+
+
+def test_workload_generators(built):
+    from rna_algos_amd import workloads as W
+    assert np.array_equal(W.synthetic_seq(300, 4096), O.splitmix_seq(300, 4096))
+    lens = W.batch_lengths()
+    assert lens.min() >= 256 and lens.max() <= 2048 and lens.shape == (10000,)
+    assert abs(lens.sum() - 1.1444e7) < 1e4  # ~1.15e7 nt
+    assert abs(W.pair_cost(lens).sum() / 4.04e12 - 1) < 0.01
+    f = W.paired_fraction(W.synthetic_seq(1024, 1024))
+    assert 0.35 < f < 0.40

@@ -1,0 +1,189 @@
+"""CPU suite, part 1: pins the oracle (oracle/*.c) — the restatement of the reference's
+McCaskill path that every GPU parity test compares against.
+
+PARITY UNPINNED by the reference itself (no Rust toolchain here, tables live in the absent
+rna-ss-params crate, the reference's only test is a range assertion), so the oracle is
+pinned by: (1) an exhaustive f64 structure enumeration, (2) an all-zero-table structure
+count computed by an independent integer DP, (3) the reference's own range assertion on
+its own fixture, (4) committed self-golden vectors (drift guard)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def unpack(packed, n):
+    m = np.full((n, n), -1.0, dtype=np.float64)
+    off = 0
+    for d in range(n):
+        idx = np.arange(n - d)
+        m[idx, idx + d] = packed[off:off + n - d]
+        off += n - d
+    return m
+
+
+def canon(a, b):
+    return (a + b == 3) or (a + b == 5)
+
+
+@pytest.mark.parametrize("contra,short", [(0, 0), (1, 0), (1, 1)])
+def test_bruteforce_random(params, contra, short):
+    rng = np.random.default_rng(100 + contra * 2 + short)
+    worst_p = worst_z = 0.0
+    for trial in range(25):
+        n = int(rng.integers(1, 17 if not short else 13))
+        seq = rng.integers(0, 4, n).astype(np.uint8)
+        out, logz = O.bpp(params.ptr, seq, contra, short)
+        lz, full, cnt = O.bruteforce(params.ptr, seq, contra, short)
+        m = unpack(out, n)
+        for i in range(n):
+            for j in range(i, n):
+                if m[i, j] < -0.5:
+                    assert full[i, j] == 0.0, (seq, i, j)
+                else:
+                    worst_p = max(worst_p, abs(m[i, j] - full[i, j]))
+        worst_z = max(worst_z, abs(lz - float(logz)))
+    # logsumexp / expf are CONTRAfold's cubic approximations: ~1e-4 is their floor
+    assert worst_p < 2e-3 and worst_z < 2e-3, (worst_p, worst_z)
+
+
+@pytest.mark.parametrize("contra", [0, 1])
+def test_bruteforce_multiloops(params, contra):
+    """GC-rich sequences of length 18..21: every loop type incl. multiloops occurs."""
+    rng = np.random.default_rng(5)
+    for trial in range(4):
+        n = int(rng.integers(18, 22))
+        seq = rng.choice(np.array([1, 2, 2, 1, 3, 0], dtype=np.uint8), n)
+        out, logz = O.bpp(params.ptr, seq, contra, 0)
+        lz, full, cnt = O.bruteforce(params.ptr, seq, contra, 0)
+        assert cnt > 50
+        m = unpack(out, n)
+        pres = m >= -0.5
+        assert np.array_equal(pres, np.triu(full > 0)), "key set differs from enumeration"
+        assert np.abs(m[pres] - full[pres]).max() < 2e-3
+        assert abs(lz - float(logz)) < 2e-3
+
+
+def count_structures(seq, short):
+    """Independent integer DP: number of structures the CONTRAfold recurrences admit
+    (canonical pairs; span >= 5 unless short; hairpin loop <= 30; a closed loop with one
+    inner pair needs <= 30 unpaired bases, else >= 2 branches)."""
+    import functools
+    n = len(seq)
+    L = 30
+
+    def ok(i, j):
+        return canon(int(seq[i]), int(seq[j])) and (short or j - i + 1 >= 5)
+
+    @functools.lru_cache(None)
+    def closed(i, j):  # structures of [i..j] in which (i,j) is paired
+        if not ok(i, j):
+            return 0
+        tot = 1 if j - i - 1 <= L else 0
+        for k in range(i + 1, j - 1):
+            if k - i - 1 > L:
+                break
+            for l in range(j - 1, k, -1):
+                if (j - l - 1) + (k - i - 1) > L:
+                    break
+                tot += closed(k, l)
+        tot += multi(i + 1, j - 1, 2)
+        return tot
+
+    @functools.lru_cache(None)
+    def multi(i, j, need):  # [i..j] holds >= need branches (need in 0,1,2), rest unpaired
+        if i > j:
+            return 1 if need == 0 else 0
+        tot = multi(i + 1, j, need)  # i unpaired
+        for l in range(i + 1, j + 1):
+            c = closed(i, l)
+            if c:
+                tot += c * multi(l + 1, j, max(need - 1, 0))
+        return tot
+
+    return multi(0, n - 1, 0)
+
+
+@pytest.mark.parametrize("short", [0, 1])
+def test_zero_tables_count_structures(built, short):
+    """FoldScoreSets::new(0.) without transfer: every structure weighs 1, so
+    exp(sums_external[0][n-1]) is the number of admissible structures."""
+    from rna_algos_amd.utils import FoldScoreSets
+    zero = FoldScoreSets.new(0.0)
+    rng = np.random.default_rng(9)
+    for n in (6, 11, 17, 24, 40):
+        seq = rng.choice(np.array([1, 2, 2, 1, 3, 0], dtype=np.uint8), n)
+        _, logz = O.bpp(zero.ptr, seq, 1, short)
+        cnt = count_structures(tuple(int(x) for x in seq), bool(short))
+        assert abs(float(logz) - np.log(cnt)) < 2e-3 * max(1.0, np.log(cnt)), (n, cnt, logz)
+        if n <= 17:
+            _, _, bf = O.bruteforce(zero.ptr, seq, 1, short)
+            assert bf == cnt
+
+
+@pytest.mark.parametrize("contra", [0, 1])
+def test_reference_range_assertion_on_trnas(params, trnas, contra):
+    """tests/tests.rs:7-43: every bpp value of the 6 tRNAs lies in [-0.001, 1.001)."""
+    for _, s in trnas:
+        out, _ = O.bpp(params.ptr, s, contra, 0)
+        vals = out[out >= -0.5]
+        assert vals.size > 0
+        assert np.all((vals >= -0.001) & (vals < 1.001))
+        # a probability matrix: no base pairs with total mass much above 1
+        m = unpack(out, len(s))
+        m[m < 0] = 0
+        assert (m.sum(0) + m.sum(1)).max() < 1.01
+
+
+def test_golden_trna_vectors(params, trnas):
+    g = np.load(os.path.join(GOLD, "trna_bpp_synthetic_seed1.npz"))
+    for idx, (_, s) in enumerate(trnas):
+        for contra, name in ((0, "turner"), (1, "contra")):
+            out, lz = O.bpp(params.ptr, s, contra, 0)
+            assert np.array_equal(out, g[f"trna{idx}_{name}"])
+            assert np.float32(lz) == g[f"trna{idx}_{name}_logz"][0]
+
+
+def test_golden_checksum_n1024(params):
+    """configs[1] (n = 1024, seed 1024): ~20 s of oracle time per model; CONTRAfold only here."""
+    g = json.load(open(os.path.join(GOLD, "checksums_n1024.json")))["cases"]["n1024_seed1024_contra"]
+    s = O.splitmix_seq(1024, 1024)
+    out, lz = O.bpp(params.ptr, s, 1, 0)
+    a = out.copy()
+    a[a >= 0.9999] = 1.0
+    assert hashlib.sha256(a.tobytes()).hexdigest() == g["sha256"]
+    assert int(np.float32(lz).view(np.uint32)) == g["log_partition_bits"]
+
+
+def test_edge_cases(params):
+    # n < 5 under Turner: nothing is written, Z = 0, empty map
+    for n in (1, 2, 4):
+        out, lz = O.bpp(params.ptr, np.zeros(n, np.uint8), 0, 0)
+        assert np.all(out == -1.0) and lz == 0.0
+    # homopolymer: no canonical pair
+    out, lz = O.bpp(params.ptr, np.zeros(30, np.uint8), 0, 0)
+    assert np.all(out == -1.0) and lz == 0.0
+    out, lz = O.bpp(params.ptr, np.zeros(30, np.uint8), 1, 0)
+    assert np.all(out == -1.0)
+    eu = float(params.external_score_unpair[0])
+    assert abs(float(lz) - 30 * eu) < 1e-4
+    # invalid input -> status, not a crash
+    with pytest.raises(RuntimeError):
+        O.bpp(params.ptr, np.zeros(0, np.uint8), 0, 0)
+    with pytest.raises(RuntimeError):
+        O.bpp(params.ptr, np.array([0, 1, 9], np.uint8), 0, 0)
+
+
+def test_thread_pool_batch_equals_sequential(params):
+    rng = np.random.default_rng(2)
+    seqs = [rng.integers(0, 4, int(n)).astype(np.uint8) for n in rng.integers(5, 90, 12)]
+    outs, logz = O.bpp_batch(params.ptr, seqs, 1, 0, n_threads=4)
+    for s, o, lz in zip(seqs, outs, logz):
+        ref, ref_lz = O.bpp(params.ptr, s, 1, 0)
+        assert np.array_equal(o, ref) and lz == ref_lz
