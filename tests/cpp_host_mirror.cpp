@@ -1,0 +1,59 @@
+// The reference's own integration test (tests/tests.rs:7-43) written against the C++
+// host mirror: 6 tRNAs, both models, every bpp value in [-0.001, 1.001).
+// Exit 0 = pass, 77 = no GPU (the library refuses to run), anything else = failure.
+#include <cstdio>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "rna_algos/mccaskill_algo.hpp"
+
+using namespace rna_algos;
+
+int main(int argc, char** argv) {
+  if (argc < 2) return 2;
+  std::ifstream in(argv[1]);
+  std::vector<Seq> seqs;
+  std::string line, cur;
+  while (std::getline(in, line)) {
+    if (!line.empty() && line[0] == '>') {
+      if (!cur.empty()) seqs.push_back(bytes2seq(cur));
+      cur.clear();
+    } else {
+      cur += line;
+    }
+  }
+  if (!cur.empty()) seqs.push_back(bytes2seq(cur));
+  if (seqs.size() != 6) return 3;
+  FoldScoreSets fold_scores = FoldScoreSets::new_(0.f);
+  fold_scores.transfer(FoldScoreSets::synthetic(1));
+  try {
+    Context ctx(fold_scores);
+    const bool allows_short_hairpins = false;
+    for (const Seq& z : seqs) {
+      for (bool uses_contra_model : {false, true}) {
+        auto a = mccaskill_algo<uint8_t>(ctx, z, uses_contra_model, allows_short_hairpins).first;
+        if (a.empty()) return 4;
+        for (const auto& kv : a)
+          if (!(kv.second >= PROB_BOUND_LOWER && kv.second < PROB_BOUND_UPPER)) return 5;
+        auto f = centroid_fold<uint8_t>(a, z.size(), 4.0f);
+        for (const auto& pr : f.basepair_pos_pairs)
+          if (a.find(pr) == a.end()) return 6;
+      }
+    }
+    try {  // a byte outside ACGU: the reference panics
+      bytes2seq("ACGT");
+      return 7;
+    } catch (const RnamcError&) {
+    }
+  } catch (const RnamcError& e) {
+    if (e.status == RNAMC_ERR_NO_DEVICE) {
+      std::printf("no GPU: %s\n", e.what());
+      return 77;
+    }
+    std::printf("error: %s\n", e.what());
+    return 1;
+  }
+  std::printf("cpp host mirror ok\n");
+  return 0;
+}

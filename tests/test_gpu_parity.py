@@ -269,3 +269,13 @@ def test_device_resident_api(params):
     st = c.stats()
     assert st["n_groups"] == 1 and st["launches_outside"] > 0
     c.close()
+
+
+def test_cpp_host_mirror_reference_test(built, tmp_path):
+    """tests/tests.rs:7-43 through the C++ mirror of the crate API on the GPU."""
+    import subprocess
+    from test_host_cpu import build_cpp_mirror
+    exe = build_cpp_mirror(str(tmp_path))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rc = subprocess.call([exe, os.path.join(root, "tests", "golden", "sampled_trnas.fa")])
+    assert rc == 0

@@ -145,3 +145,23 @@ def test_workload_generators(built):
     assert abs(W.pair_cost(lens).sum() / 4.04e12 - 1) < 0.01
     f = W.paired_fraction(W.synthetic_seq(1024, 1024))
     assert 0.35 < f < 0.40
+
+
+def build_cpp_mirror(tmp_path):
+    import subprocess
+    exe = os.path.join(tmp_path, "cpp_host_mirror")
+    libdir = os.path.join(ROOT, "rna_algos_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp_host_mirror.cpp"), "-L" + libdir, "-lrnamc",
+                           "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_cpp_host_mirror_compiles_and_refuses_without_gpu(built, tmp_path):
+    """include/rna_algos/mccaskill_algo.hpp (the C++ mirror of the crate's API) builds with
+    plain g++ against the C ABI; without a GPU the program reports 'no device' (exit 77)."""
+    import subprocess
+    import torch
+    exe = build_cpp_mirror(str(tmp_path))
+    rc = subprocess.call([exe, os.path.join(ROOT, "tests", "golden", "sampled_trnas.fa")])
+    assert rc == (0 if torch.cuda.is_available() else 77)
