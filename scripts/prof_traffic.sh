@@ -1,0 +1,36 @@
+# HBM traffic of the sweep kernels from PMC counters, separate passes (no tracing domains):
+# FETCH_SIZE, WRITE_SIZE (KB at the L2's fabric side), per kernel, on a reduced batch.
+# usage: bash scripts/prof_traffic.sh <tag> [bench args]
+set -e
+TAG=${1:-r01}; shift || true
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/prof_traffic_$TAG
+rm -rf $OUT && mkdir -p $OUT
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --output-format csv -d $OUT/$C -- python3 $R/bench.py "$@" --no-cpu-baseline --steps 1 --warmup 0 > $OUT/bench_$C.json 2> $OUT/$C.err || { tail -5 $OUT/$C.err; exit 1; }
+done
+python3 - <<PY
+import csv, glob, json, collections
+out = "$OUT"
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+n = collections.defaultdict(int)
+for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        kn = r["Kernel_Name"]
+        k = "k_outside" if "k_outside" in kn else "k_inside" if "k_inside" in kn else "other"
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "FETCH_SIZE": n[k] += 1
+b = json.loads(open(out + "/bench_FETCH_SIZE.json").read().strip().splitlines()[-1])
+res = {"bench_config": b["config"], "launches": dict(n), "counters_KB": {k: dict(v) for k, v in agg.items()}}
+for k in ("k_inside", "k_outside"):
+    f, w = agg[k]["FETCH_SIZE"] * 1024, agg[k]["WRITE_SIZE"] * 1024
+    # gfx950: FETCH_SIZE tallies 128-B requests at 64 B for wide streaming reads (guide §HBM);
+    # our reads are 4 B/lane (256 B per wave): uncalibrated, both readings are given
+    res[k] = {"fetch_bytes_raw": f, "fetch_bytes_x2": 2 * f, "write_bytes": w, "launches": n[k],
+              "per_launch_raw": (f + w) / max(n[k], 1), "per_launch_x2": (2 * f + w) / max(n[k], 1)}
+res["roofline"] = b["roofline"]; res["roofline_inside"] = b["roofline_inside"]
+json.dump(res, open(out + "/traffic.json", "w"), indent=1)
+print(json.dumps(res, indent=1)[:3000])
+PY
+find $OUT -name "*counter_collection.csv" -delete
