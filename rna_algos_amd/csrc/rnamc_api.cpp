@@ -69,8 +69,11 @@ struct DeviceGuard {
 };
 
 uint64_t tri_pad_of(uint32_t n) {
-  // + 64 floats: kernels read up to one wave past a diagonal's end (values masked)
+  // + 64 floats: kernels read up to one wave past a diagonal's end (values masked).
+  // Column-major slots pad every column to 16 floats: 16 (m+1)(8m + r) floats for n columns.
   uint64_t t = static_cast<uint64_t>(n) * (n + 1ull) / 2ull;
+  const uint64_t m = n >> 4, r = n & 15ull;
+  t = std::max<uint64_t>(t, 16ull * (m + 1ull) * (8ull * m + r));
   return ((t + 63ull) & ~63ull) + 64ull;
 }
 
@@ -466,15 +469,16 @@ int rnamc_debug_fetch(rnamc_ctx* c, uint32_t seq_idx, int which, float* out_nxn)
   HIPCHK(hipDeviceSynchronize());
   const uint32_t n = sd->n;
   const uint64_t tri = static_cast<uint64_t>(n) * (n + 1ull) / 2ull;
-  std::vector<float> packed(tri);
+  std::vector<float> packed(sd->tri_pad);  // column-major slots are a little larger than tri
   HIPCHK(hipMemcpy(packed.data(), c->d_ws + sd->ws_off + static_cast<uint64_t>(kMat[which]) * sd->tri_pad,
-                   tri * sizeof(float), hipMemcpyDeviceToHost));
+                   static_cast<size_t>(sd->tri_pad) * sizeof(float), hipMemcpyDeviceToHost));
   const float nan = std::numeric_limits<float>::quiet_NaN();
   for (uint64_t x = 0; x < static_cast<uint64_t>(n) * n; x++) out_nxn[x] = nan;
   for (uint32_t i = 0; i < n; i++)
     for (uint32_t j = i; j < n; j++) {
       const uint64_t d = j - i;
-      const uint64_t idx = row_major ? (static_cast<uint64_t>(i) * n - static_cast<uint64_t>(i) * (i - 1ull) / 2ull + d)
+      const uint64_t cm = j >> 4, cr = j & 15u;
+      const uint64_t idx = row_major ? (16ull * (cm + 1ull) * (8ull * cm + cr) + i)  // column-major
                                      : (d * n - d * (d - 1ull) / 2ull + i);
       out_nxn[static_cast<uint64_t>(i) * n + j] = packed[idx];
     }

@@ -25,11 +25,11 @@ enum Mat : int {
   M_MBC = 2,  // multibranch_close_scores            diag-major
   M_Z = 3,    // sums_external                       diag-major
   M_Q1D = 4,  // sums_1ormore_basepairs              diag-major
-  M_Q1R = 5,  // sums_1ormore_basepairs              row-major
+  M_Q1C = 5,  // sums_1ormore_basepairs              column-major, shifted one row (see col_off)
   M_ZRE = 6,  // sums_rightmost_basepairs_external   diag-major (inside pass)
-  M_PM = 6,   // probs_multibranch                   row-major  (outside pass, same slot)
+  M_PM = 6,   // probs_multibranch                   column-major (outside pass, same slot)
   M_QM = 7,   // sums_multibranch                    diag-major (inside pass)
-  M_PM2 = 7,  // probs_multibranch2                  row-major  (outside pass, same slot)
+  M_PM2 = 7,  // probs_multibranch2                  column-major (outside pass, same slot)
   M_W = 8,    // (P + mbclose) - Qb of a pair        diag-major (outside pass)
   M_ZRM = 9,  // sums_rightmost_basepairs_multibranch diag-major (CONTRAfold, inside pass)
   M_P = 9,    // log basepair_probs                  diag-major (outside pass, same slot)

@@ -197,6 +197,16 @@ __device__ __forceinline__ uint32_t tri_off(uint32_t n, uint32_t d) {
   return d * n - (d * (d - 1u)) / 2u;
 }
 
+// Column-major packed triangle with every column padded to a multiple of 16 f32:
+// element (k, j), k <= j, at col_off(j) + k.  A lane that walks one column reads
+// 64-byte-aligned blocks of its own, so a walk over k fetches exactly the bytes it
+// uses (the multibranch half of the pair probabilities walks columns of
+// probs_multibranch{,2} and of sums_1ormore_basepairs).
+__device__ __forceinline__ uint32_t col_off(uint32_t j) {
+  const uint32_t m = j >> 4, r = j & 15u;
+  return 16u * (m + 1u) * (8u * m + r);
+}
+
 __device__ __forceinline__ bool canonical(int a, int b) {
   // AU CG GC GU UA UG  <=>  a+b == 3 (AU, CG) or {a,b} == {G,U}
   return (a + b == 3) || (a + b == 5);
@@ -660,7 +670,7 @@ __device__ __forceinline__ void inside_sums_cell(const DeviceBatch& b, const Seq
   q.m[M_QM][od] = s2;
   s1 = lse(s1, s2, tab);
   q.m[M_Q1D][od] = s1;
-  q.m[M_Q1R][tri_off(n, i) + d] = s1;
+  if (i >= 1) q.m[M_Q1C][col_off(i + d) + i - 1] = s1;  // column j, shifted one row up
 }
 
 // One launch of the inside sweep: blocks [0, blocks_sums) fold diagonal d, the
@@ -761,9 +771,9 @@ __device__ __forceinline__ void outside_mb_cell(const DeviceBatch& b, const Seq&
   for (; t <= cnt_wave; t++)
     step(ldu(w + tri_off(n, d + t), i4), ldu(q1d + tri_off(n, t - 2) + d + 1, i4), t);
   if (valid) {
-    const uint32_t orow = tri_off(n, i) + d;
-    q.m[M_PM][orow] = pm;
-    q.m[M_PM2][orow] = pm2;
+    const uint32_t ocol = col_off(j) + i;
+    q.m[M_PM][ocol] = pm;
+    q.m[M_PM2][ocol] = pm2;
   }
 }
 
@@ -827,17 +837,18 @@ __device__ __forceinline__ void outside_pair_tail(const DeviceBatch& b, const Se
     }
   }
   if (CONTRA) mun = b.params->contra.multibranch_score_unpair;
-  const float* __restrict__ q1r = q.m[M_Q1R];
-  const float* __restrict__ pmr = q.m[M_PM];
-  const float* __restrict__ pm2r = q.m[M_PM2];
-  const uint32_t iend = paired ? i : 0u;
-  const uint32_t i4 = i * 4u;
-  // unconditional loads (in bounds: see outside_mb_cell), validity applied to values:
+  // Column walks: probs_multibranch{,2}[k][j] = column j, sums_1ormore_basepairs[k+1][i-1]
+  // = column i-1 stored one row up.  Each lane streams its own three columns in
+  // 32-byte pieces (two dwordx4 per column and chunk); a column's padding makes a read
+  // past the lane's own rows harmless, validity is applied to the values:
   //   k < iend   : the step exists for this lane
   //   k+2 <= iend: the interval [k+1, i-1] is not empty
-  auto ld_x = [&](uint32_t k) { return ldu(q1r + tri_off(n, k + 1) - (k + 2), i4); };
-  auto ld_y = [&](uint32_t k) { return ldu(pmr + tri_off(n, k) + d - k, i4); };
-  auto ld_y2 = [&](uint32_t k) { return ldu(pm2r + tri_off(n, k) + d - k, i4); };
+  const uint32_t iend = paired ? i : 0u;
+  const uint32_t j = i + d;
+  const float4* __restrict__ ycol = reinterpret_cast<const float4*>(q.m[M_PM] + col_off(j));
+  const float4* __restrict__ y2col = reinterpret_cast<const float4*>(q.m[M_PM2] + col_off(j));
+  const float4* __restrict__ xcol =
+      reinterpret_cast<const float4*>(q.m[M_Q1C] + col_off(i >= 1 ? i - 1 : 0));
   auto step = [&](float x, float y, float y2, uint32_t k) {
     const bool vy = k < iend;
     x = (k + 2 <= iend) ? x : kNegInf;
@@ -851,26 +862,31 @@ __device__ __forceinline__ void outside_pair_tail(const DeviceBatch& b, const Se
     }
     p = lse(p, sa + x + y, tab);
   };
+  static_assert(kUE % 4 == 0, "column walks move whole float4");
   struct EBuf {
-    float xs[kUE], ys[kUE], y2s[kUE];
+    float4 xs[kUE / 4], ys[kUE / 4], y2s[kUE / 4];
   };
-  // steps 0 .. imax_wave-1
+  // steps 0 .. imax_wave-1, whole chunks (the padding covers the last partial chunk)
   if (b.debug & 32) imax_wave = 0;
-  uint32_t k = pingpong<EBuf, kUE>(
-      0u, imax_wave / kUE,
+  pingpong<EBuf, kUE>(
+      0u, (imax_wave + kUE - 1) / kUE,
       [&](EBuf& B, uint32_t k0) {
 #pragma unroll
-        for (int u = 0; u < kUE; u++) {
-          B.xs[u] = ld_x(k0 + u);
-          B.ys[u] = ld_y(k0 + u);
-          B.y2s[u] = ld_y2(k0 + u);
+        for (int u = 0; u < kUE / 4; u++) {
+          B.xs[u] = xcol[k0 / 4 + u];
+          B.ys[u] = ycol[k0 / 4 + u];
+          B.y2s[u] = y2col[k0 / 4 + u];
         }
       },
       [&](const EBuf& B, uint32_t k0) {
 #pragma unroll
-        for (int u = 0; u < kUE; u++) step(B.xs[u], B.ys[u], B.y2s[u], k0 + u);
+        for (int u = 0; u < kUE / 4; u++) {
+          step(B.xs[u].x, B.ys[u].x, B.y2s[u].x, k0 + 4 * u);
+          step(B.xs[u].y, B.ys[u].y, B.y2s[u].y, k0 + 4 * u + 1);
+          step(B.xs[u].z, B.ys[u].z, B.y2s[u].z, k0 + 4 * u + 2);
+          step(B.xs[u].w, B.ys[u].w, B.y2s[u].w, k0 + 4 * u + 3);
+        }
       });
-  for (; k < imax_wave; k++) step(ld_x(k), ld_y(k), ld_y2(k), k);
   if (paired && p > kNegInf) {
     q.m[M_P][od] = p;
     q.m[M_W][od] = p + q.m[M_MBC][od] - qb_ij;
