@@ -1,0 +1,66 @@
+"""Mirror of the reference binary `mccaskill_algo` (src/bin/mccaskill_algo.rs:6-113):
+
+    python -m rna_algos_amd.bin.mccaskill_algo -i FASTA -o OUT [-c] [-t N]
+
+Same flags, same output text: a `# Format = ...` header, then per record
+`\\n\\n>{index}\\n` followed by `i,j,p ` triples (Rust `{}` formatting of the f32).  The
+reference iterates a hash map, so the order of the triples inside a record is
+unspecified there; here it is ascending (i, j).  The whole FASTA goes to the GPU as one
+batch instead of one thread-pool task per record; `-t` is accepted and ignored."""
+import argparse
+import sys
+
+import numpy as np
+
+from ..utils import FoldScoreSets, read_fasta
+from ..mccaskill_algo import mccaskill_algo_batch
+
+HEADER = ("# Format = >{RNA sequence id} {line break} {basepairing left nucleotide}, "
+          "{basepairing right nucleotide}, {basepairing probability} ...")
+
+
+def fmt_f32(x):
+    """Rust's `{}` for f32: shortest decimal that round-trips, never scientific."""
+    return np.format_float_positional(np.float32(x), unique=True, trim="-")
+
+
+def probs2str(mat):
+    """src/bin/mccaskill_algo.rs:104-113 over a BppMatrix."""
+    out = []
+    n = mat.n
+    idx = np.nonzero(mat.packed >= -0.5)[0]
+    # packed index -> (i, j); emit ascending (i, j)
+    d = np.zeros(idx.shape[0], dtype=np.int64)
+    starts = np.array([dd * n - dd * (dd - 1) // 2 for dd in range(n + 1)], dtype=np.int64)
+    d = np.searchsorted(starts, idx, side="right") - 1
+    i = idx - starts[d]
+    j = i + d
+    order = np.lexsort((j, i))
+    for k in order:
+        out.append(f"{int(i[k])},{int(j[k])},{fmt_f32(mat.packed[idx[k]])} ")
+    return "".join(out)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="mccaskill_algo")
+    ap.add_argument("-i", "--input_file_path", required=True)
+    ap.add_argument("-o", "--output_file_path", required=True)
+    ap.add_argument("-t", "--num_threads", type=int, default=0)
+    ap.add_argument("-c", "--uses_contra_model", action="store_true")
+    args = ap.parse_args(argv)
+    recs = read_fasta(args.input_file_path)
+    fold_score_sets = FoldScoreSets.new(0.0)
+    fold_score_sets.transfer()
+    mats, _ = mccaskill_algo_batch([s for _, s in recs], args.uses_contra_model, False,
+                                   fold_score_sets)
+    buf = [HEADER]
+    for rna_id, m in enumerate(mats):
+        buf.append(f"\n\n>{rna_id}\n")
+        buf.append(probs2str(m))
+    with open(args.output_file_path, "w") as fh:
+        fh.write("".join(buf))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

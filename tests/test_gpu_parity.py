@@ -279,3 +279,52 @@ def test_cpp_host_mirror_reference_test(built, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     rc = subprocess.call([exe, os.path.join(root, "tests", "golden", "sampled_trnas.fa")])
     assert rc == 0
+
+
+def test_cli_binaries(ctx, params, trnas, tmp_path):
+    """The two binaries' file formats end to end on the reference fixture
+    (src/bin/mccaskill_algo.rs:94-113, src/bin/centroid_fold.rs:165-207)."""
+    from rna_algos_amd.bin import mccaskill_algo as cli_m, centroid_fold as cli_c
+    from rna_algos_amd.bin.mccaskill_algo import HEADER, fmt_f32
+    from rna_algos_amd import utils
+    fa = utils.EXAMPLE_FASTA_FILE_PATH
+    utils._default = params  # the table set `transfer()` draws from in this test
+    out = os.path.join(tmp_path, "bpp.dat")
+    assert cli_m.main(["-i", fa, "-o", out, "-c"]) == 0
+    text = open(out).read()
+    assert text.startswith(HEADER + "\n\n>0\n")
+    blocks = text[len(HEADER):].split("\n\n>")[1:]
+    assert len(blocks) == len(trnas)
+    for idx, blk in enumerate(blocks):
+        head, body = blk.split("\n", 1)
+        assert int(head) == idx
+        got = {}
+        for tok in body.split():
+            i, j, p = tok.split(",")
+            got[(int(i), int(j))] = np.float32(p)
+        ref, _ = O.bpp(params.ptr, trnas[idx][1], True, False)
+        n = len(trnas[idx][1])
+        want = {}
+        off = 0
+        for d in range(n):
+            for i in np.nonzero(ref[off:off + n - d] >= -0.5)[0]:
+                want[(int(i), int(i) + d)] = ref[off + i]
+            off += n - d
+        assert got.keys() == want.keys()
+        assert all(got[k] == want[k] for k in want)  # printed f32 round-trips
+    outdir = os.path.join(tmp_path, "folds")
+    assert cli_c.main(["-i", fa, "-o", outdir, "-c"]) == 0
+    files = sorted(os.listdir(outdir))
+    assert len(files) == 18 and "centroid_threshold=0.0078125.fa" in files \
+        and "centroid_threshold=1024.fa" in files
+    body = open(os.path.join(outdir, "centroid_threshold=4.fa")).read()
+    recs = body.split("\n")
+    assert len(recs) == 2 * len(trnas) and not body.endswith("\n")
+    for idx, (_, s) in enumerate(trnas):
+        assert recs[2 * idx] == f">{idx}"
+        ref_bpp, _ = O.bpp(params.ptr, s, True, False)
+        pairs, _ = O.centroid_fold(ref_bpp, len(s), 4.0)
+        want = ["."] * len(s)
+        for i, j in pairs:
+            want[i], want[j] = "(", ")"
+        assert recs[2 * idx + 1] == "".join(want)

@@ -165,3 +165,19 @@ def test_cpp_host_mirror_compiles_and_refuses_without_gpu(built, tmp_path):
     exe = build_cpp_mirror(str(tmp_path))
     rc = subprocess.call([exe, os.path.join(ROOT, "tests", "golden", "sampled_trnas.fa")])
     assert rc == (0 if torch.cuda.is_available() else 77)
+
+
+def test_cli_text_formatting(built):
+    """Rust `{}` formatting of f32 (shortest round-trip, positional) used by the binaries'
+    text formats (src/bin/mccaskill_algo.rs:104-113, src/bin/centroid_fold.rs:138,180-191)."""
+    from rna_algos_amd.bin.mccaskill_algo import fmt_f32, probs2str, HEADER
+    from rna_algos_amd.mccaskill_algo import BppMatrix, bpp_index, bpp_len
+    assert fmt_f32(1.0) == "1" and fmt_f32(0.5) == "0.5" and fmt_f32(2.0 ** -7) == "0.0078125"
+    assert fmt_f32(1024.0) == "1024" and fmt_f32(np.float32(0.1)) == "0.1"
+    assert fmt_f32(np.float32(1e-7)) == "0.0000001" and fmt_f32(np.float32(1) / 3) == "0.33333334"
+    n = 7
+    packed = np.full(bpp_len(n), -1.0, dtype=np.float32)
+    packed[bpp_index(n, 1, 6)] = 0.25
+    packed[bpp_index(n, 0, 5)] = np.float32(0.1)
+    assert probs2str(BppMatrix(n, packed)) == "0,5,0.1 1,6,0.25 "
+    assert HEADER.startswith("# Format = >{RNA sequence id}")
