@@ -468,7 +468,6 @@ int rnamc_debug_fetch(rnamc_ctx* c, uint32_t seq_idx, int which, float* out_nxn)
   if (!guard.ok) return RNAMC_ERR_NO_DEVICE;
   HIPCHK(hipDeviceSynchronize());
   const uint32_t n = sd->n;
-  const uint64_t tri = static_cast<uint64_t>(n) * (n + 1ull) / 2ull;
   std::vector<float> packed(sd->tri_pad);  // column-major slots are a little larger than tri
   HIPCHK(hipMemcpy(packed.data(), c->d_ws + sd->ws_off + static_cast<uint64_t>(kMat[which]) * sd->tri_pad,
                    static_cast<size_t>(sd->tri_pad) * sizeof(float), hipMemcpyDeviceToHost));

@@ -13,17 +13,22 @@
 //  * the sweep is by anti-diagonal d = j - i; all cells of one diagonal of ALL
 //    sequences of a group are independent and are processed by one launch;
 //  * one lane owns one cell (i, i+d); lanes of a wave own consecutive i, so with
-//    the diagonal-major / row-major packed layouts of rnamc_internal.h every
-//    operand of every inner loop is a coalesced 256-B wave access;
+//    the packed layouts of rnamc_internal.h the operands of the inside folds and of
+//    probs_multibranch are contiguous 256-B wave accesses, and the pair-probability
+//    tail streams lane-private columns in 64-byte pieces (it uses every byte it fetches);
 //  * the reduction index k is walked sequentially per lane (order is part of
 //    the result); parallelism comes from cells x sequences x independent folds,
-//    not from k.  Operands of the next 8 k-steps are fetched into registers
-//    while the current 8 are folded (the loads do not depend on the chain);
-//  * the 8-piece cubic of logsumexp is evaluated branch-free: a 3-compare binary
-//    search gives the piece, one ds_read_b128 fetches its 4 coefficients from LDS;
-//  * each launch carries two independent roles in disjoint blocks: inside =
-//    {folds of diagonal d, closing-pair block of diagonal d+1}, outside =
-//    {probs_multibranch folds, pair probabilities} of diagonal d.
+//    not from k.  Operands of the next chunk of k-steps are fetched into a second
+//    register buffer while the current chunk is folded (loads do not depend on the chain);
+//  * the 8-piece cubic of logsumexp is evaluated branch-free: a 42-cell LDS table
+//    and one compare give the piece, one ds_read_b128 its 4 coefficients;
+//  * hot loops carry no exec-mask branches: loads are unconditional (matrices are
+//    padded), lane validity is applied to the loaded values;
+//  * each launch carries independent roles in disjoint blocks: inside = {folds of
+//    diagonal d, closing-pair block of diagonal d+1}, outside = {probs_multibranch of d,
+//    multibranch half of the pair probabilities of d, 2-loop half of d-1};
+//  * block ids walk over sequences first so that the 8 XCDs get equal mixes of
+//    light and heavy blocks; heavy blocks are issued first.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -320,42 +325,6 @@ struct Turner {
     return hs + pen(bi, bj);
   }
 
-  // get_2loop_score, src/utils.rs:207-366.  (i,j) closes, (k,l) is enclosed;
-  // a = k-i-1 and b = j-l-1 unpaired bases on the two sides.
-  __device__ float twoloop(const uint8_t* s, uint32_t i, uint32_t j, uint32_t k, uint32_t l,
-                           uint32_t a, uint32_t b) const {
-    const int ci = s[i], cj = s[j], ak = s[k], al = s[l];
-    if (a == 0 && b == 0) return t.stack_scores[ci][cj][ak][al];
-    if (a == 0 || b == 0) {
-      const uint32_t len = a + b;
-      if (len == 1) return t.bulge_scores_init[1] + t.stack_scores[ci][cj][ak][al];
-      return t.bulge_scores_init[len] + pen(ci, cj) + pen(ak, al);
-    }
-    if (a == 1 && b == 1) return t.interior_scores_1x1[ci][cj][s[i + 1]][s[j - 1]][ak][al];
-    if (a == 1 && b == 2)
-      return t.interior_scores_1x2[ci][cj][s[i + 1]][s[j - 1]][s[j - 2]][ak][al];
-    if (a == 2 && b == 1)
-      return t.interior_scores_1x2[al][ak][s[j - 1]][s[i + 2]][s[i + 1]][cj][ci];
-    if (a == 2 && b == 2)
-      return t.interior_scores_2x2[ci][cj][s[i + 1]][s[j - 1]][s[i + 2]][s[j - 2]][ak][al];
-    const uint32_t diff = a > b ? a - b : b - a;
-    const int m0 = s[i + 1], m1 = s[j - 1], m2 = s[l + 1], m3 = s[k - 1];
-    float mm;
-    if (a == 1 || b == 1) {
-      mm = t.terminal_mismatch_scores_1xmany[ci][cj][m0][m1] +
-           t.terminal_mismatch_scores_1xmany[al][ak][m2][m3];
-    } else if ((a == 2 && b == 3) || (a == 3 && b == 2)) {
-      mm = t.terminal_mismatch_scores_2x3[ci][cj][m0][m1] +
-           t.terminal_mismatch_scores_2x3[al][ak][m2][m3];
-    } else {
-      mm = t.terminal_mismatch_scores_interior[ci][cj][m0][m1] +
-           t.terminal_mismatch_scores_interior[al][ak][m2][m3];
-    }
-    return t.interior_scores_init[a + b] +
-           fmaxf(t.ninio_coeff * static_cast<float>(diff), t.ninio_max) + mm + pen(ci, cj) +
-           pen(ak, al);
-  }
-
   // get_multibranch_close_score, src/utils.rs:368-382
   __device__ float mbclose(const uint8_t* s, uint32_t /*n*/, uint32_t i, uint32_t j) const {
     const int ci = s[i], cj = s[j];
@@ -404,36 +373,6 @@ struct Contra {
     uint32_t len = j - i - 1;
     if (len > RNAMC_MAX_LOOP_LEN) len = RNAMC_MAX_LOOP_LEN;
     return f.hairpin_scores_len_cumulative[len] + junction_single(s, i, j);
-  }
-
-  __device__ float twoloop(const uint8_t* s, uint32_t i, uint32_t j, uint32_t k, uint32_t l,
-                           uint32_t a, uint32_t b) const {
-    const int ak = s[k], al = s[l];
-    float sc;
-    if (a == 0 && b == 0) {
-      sc = f.stack_scores[s[i]][s[j]][ak][al];
-    } else if (a == 0 || b == 0) {
-      const uint32_t len = a + b;
-      float s0 = 0.f;
-      if (len == 1) s0 = f.bulge_scores_0x1[a == 1 ? s[i + 1] : s[j - 1]];
-      sc = s0 + f.bulge_scores_len_cumulative[len - 1] + junction_single(s, i, j) +
-           junction_single(s, l, k);
-    } else {
-      float s0;
-      if (a == b) {
-        const float s11 = (a + b == 2) ? f.interior_scores_1x1[s[i + 1]][s[j - 1]] : 0.f;
-        s0 = s11 + f.interior_scores_symmetric_cumulative[a - 1];
-      } else {
-        const uint32_t diff = a > b ? a - b : b - a;
-        s0 = f.interior_scores_asymmetric_cumulative[diff - 1];
-      }
-      const float se = (a <= RNAMC_MAX_INTERIOR_EXPLICIT && b <= RNAMC_MAX_INTERIOR_EXPLICIT)
-                           ? f.interior_scores_explicit[a - 1][b - 1]
-                           : 0.f;
-      sc = s0 + se + f.interior_scores_len_cumulative[a + b - 2] + junction_single(s, i, j) +
-           junction_single(s, l, k);
-    }
-    return sc + f.basepair_scores[ak][al];
   }
 
   __device__ float mbclose(const uint8_t* s, uint32_t n, uint32_t i, uint32_t j) const {

@@ -1,0 +1,70 @@
+// HBM streaming rate of the sweep's access pattern: every step of a wave reads one
+// contiguous piece of a DIFFERENT row (stride ~8 KB), shifted by one float per step
+// (so vector loads are only 4-byte aligned), 3 independent streams, 8 steps in flight.
+// W = floats per lane per load (1: dword, 2: dwordx2, 4: dwordx4).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+template <int W> struct __attribute__((packed, aligned(4))) Vec { float v[W]; };
+
+template <int W>
+__global__ void __launch_bounds__(256) k(const float* __restrict__ a, const float* __restrict__ b,
+                                         const float* __restrict__ c, float* out, uint32_t rows,
+                                         uint32_t stride, uint32_t steps) {
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64;
+  const uint32_t lane = threadIdx.x & 63;
+  // each wave owns a window of the row: column offset col0 .. col0 + 64*W
+  const uint32_t waves_per_row = stride / (64 * W) - 1;
+  const uint32_t col0 = (wave % waves_per_row) * 64 * W;
+  const uint32_t row0 = (wave / waves_per_row) * 7919u % rows;
+  float acc[W] = {0};
+  for (uint32_t t0 = 0; t0 < steps; t0 += 8) {
+    Vec<W> va[8], vb[8], vc[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const uint32_t t = t0 + u;
+      const size_t ra = (size_t)((row0 + rows - t % rows) % rows) * stride + col0 + (t & 31) + lane * W;
+      const size_t rb = (size_t)((row0 + t) % rows) * stride + col0 + lane * W;
+      va[u] = *reinterpret_cast<const Vec<W>*>(a + ra);
+      vb[u] = *reinterpret_cast<const Vec<W>*>(b + rb);
+      vc[u] = *reinterpret_cast<const Vec<W>*>(c + rb);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+#pragma unroll
+      for (int w = 0; w < W; w++) acc[w] += va[u].v[w] + vb[u].v[w] * vc[u].v[w];
+  }
+  float s = 0;
+  for (int w = 0; w < W; w++) s += acc[w];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int W>
+void run(const float* a, const float* b, const float* c, float* out, uint32_t rows, uint32_t stride) {
+  const uint32_t steps = 1024;
+  const uint32_t waves = 256 * 4 * 8 * 4;  // 4 rounds of 8 waves/SIMD
+  dim3 grid(waves / 4), block(256);
+  hipLaunchKernelGGL(k<W>, grid, block, 0, 0, a, b, c, out, rows, stride, 64);
+  hipDeviceSynchronize();
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0);
+  hipLaunchKernelGGL(k<W>, grid, block, 0, 0, a, b, c, out, rows, stride, steps);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  double bytes = (double)waves * steps * 3 * 64 * W * 4;
+  printf("W=%d: %.2f ms, %.2f TB/s (%.1f GB moved)\n", W, ms, bytes / ms / 1e9, bytes / 1e9);
+}
+
+int main() {
+  const uint32_t stride = 2048 + 64, rows = 400000;  // 3.4 GB per array
+  float *a, *b, *c, *out;
+  size_t n = (size_t)rows * stride + 4096;
+  hipMalloc(&a, n * 4); hipMalloc(&b, n * 4); hipMalloc(&c, n * 4); hipMalloc(&out, 4 * 256 * 4 * 8 * 4 * 64);
+  hipMemset(a, 0, n * 4); hipMemset(b, 0, n * 4); hipMemset(c, 0, n * 4);
+  run<1>(a, b, c, out, rows, stride);
+  run<2>(a, b, c, out, rows, stride);
+  run<4>(a, b, c, out, rows, stride);
+  run<1>(a, b, c, out, rows, stride);
+  return 0;
+}
