@@ -75,6 +75,22 @@ def inside_bytes(lengths, f, contra):
     return (16.0 + (4.0 if contra else 0.0)) * T + 4.0 * 496.0 * f * n2 / 2.0 + 20.0 * n2 / 2.0
 
 
+def pmc_traffic_per_launch(kernel, total_T, launches):
+    """HBM bytes per launch of `kernel` from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs, scripts/prof_traffic.sh; FETCH_SIZE doubled as the gfx950 guide
+    prescribes), scaled from that pass's workload to this one by sum n(n^2-1)/6.  None when the
+    profile is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic_batch1000.json")
+    try:
+        t = json.load(open(path))
+        from rna_algos_amd import workloads as W
+        ref_T = float(W.pair_cost(W.batch_lengths(1000)).sum())
+        k = t[kernel]
+        return (k["fetch_bytes_x2"] + k["write_bytes"]) * (total_T / ref_T) / max(launches, 1)
+    except Exception:
+        return None
+
+
 def cpu_baseline(params, seqs, contra, budget_s):
     """Oracle ("port" of the reference's CPU path) on a bounded, length-stratified sample,
     one sequence per thread on all host cores (as the reference's thread pool does)."""
@@ -255,7 +271,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": ach_out / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic_per_launch("k_outside", float(W.pair_cost(lens.astype(np.float64)).sum()),
+                                                  l_out / steps) if args.workload == "batch10k" and not contra else None,
+                "traffic_source": "profiles/r01_traffic_batch1000.json (separate --pmc passes, scaled by "
+                                  "sum n(n^2-1)/6)",
                 "algorithmic_bytes_per_launch": b_out / max(l_out / steps, 1),
                 "avg_launch_ms": avg_out_ms,
                 "launches_per_step": l_out // steps,
