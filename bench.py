@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--model", default="turner", choices=["turner", "contra"])
     ap.add_argument("--batch-count", type=int, default=10000)
     ap.add_argument("--group-max-seqs", type=int, default=0)
+    ap.add_argument("--group-max-nt", type=int, default=0)
+    ap.add_argument("--group-ws-gb", type=int, default=0)
     ap.add_argument("--param-seed", type=int, default=1)
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -186,6 +188,10 @@ def main():
     ctx.set("profile", 1)
     if args.group_max_seqs:
         ctx.set("group_max_seqs", args.group_max_seqs)
+    if args.group_max_nt:
+        ctx.set("group_max_nt", args.group_max_nt)
+    if args.group_ws_gb:
+        ctx.set("group_ws_bytes", args.group_ws_gb << 30)
 
     # inputs resident in HBM before the timed region; outputs stay in HBM
     d_bases = torch.from_numpy(np.concatenate(my_seqs)).to(dev)

@@ -43,7 +43,8 @@ struct rnamc_ctx {
   hipStream_t own_stream = nullptr;
   std::mutex mu;
   // knobs
-  int64_t group_max_seqs = 512;
+  int64_t group_max_seqs = 8192;
+  int64_t group_max_nt = 2ll << 20;  // a group holds ~2M nucleotides (or 64 GB of DP state)
   int64_t group_ws_bytes = 64ll << 30;
   int64_t block_threads = 256;
   int64_t profile = 0;
@@ -145,7 +146,7 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
   const uint64_t ws_cap_floats = static_cast<uint64_t>(std::max<int64_t>(c->group_ws_bytes, 1)) / 4;
   uint64_t max_group_floats = 0;
   {
-    uint64_t cur = 0;
+    uint64_t cur = 0, cur_nt = 0;
     uint32_t cnt = 0;
     for (uint32_t x = 0; x < n_seqs; x++) {
       const uint32_t s = order[x];
@@ -154,9 +155,14 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
       const uint64_t cidx_words = (tri_pad_of(n) + 1) / 2;  // u16 per cell, in 4-byte units
       const uint64_t ccnt_words = (static_cast<uint64_t>(n) + 63) & ~63ull;
       const uint64_t need = tri_pad_of(n) * M_COUNT + pk_words + cidx_words + ccnt_words;
-      if (cnt > 0 && (cnt >= static_cast<uint32_t>(c->group_max_seqs) || cur + need > ws_cap_floats)) {
+      // a launch should carry enough cells to fill the chip: short sequences go into
+      // larger groups (bounded by nucleotides, sequences and workspace bytes)
+      if (cnt > 0 && (cnt >= static_cast<uint32_t>(c->group_max_seqs) ||
+                      cur_nt + n > static_cast<uint64_t>(c->group_max_nt) ||
+                      cur + need > ws_cap_floats)) {
         max_group_floats = std::max(max_group_floats, cur);
         cur = 0;
+        cur_nt = 0;
         cnt = 0;
       }
       if (cnt == 0) c->group_begin.push_back(static_cast<uint32_t>(c->descs.size()));
@@ -173,6 +179,7 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
       sd.ccnt_off = sd.cidx_off + cidx_words;
       c->descs.push_back(sd);
       cur += need;
+      cur_nt += n;
       cnt++;
     }
     max_group_floats = std::max(max_group_floats, cur);
@@ -349,6 +356,8 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
   const std::string k(name);
   if (k == "group_max_seqs" && value >= 1) {
     c->group_max_seqs = std::min<int64_t>(value, 65535);
+  } else if (k == "group_max_nt" && value >= 1) {
+    c->group_max_nt = value;
   } else if (k == "group_ws_bytes" && value >= 4) {
     c->group_ws_bytes = value;
   } else if (k == "block_threads" && value >= 64 && value <= 1024 && value % 64 == 0) {

@@ -328,3 +328,25 @@ def test_cli_binaries(ctx, params, trnas, tmp_path):
         for i, j in pairs:
             want[i], want[j] = "(", ")"
         assert recs[2 * idx + 1] == "".join(want)
+
+
+@pytest.mark.parametrize("seed", [2, 3])
+def test_other_tables_and_low_complexity(built, seed):
+    """Other table sets (different synthetic seeds, and all-zero tables) and adversarial
+    inputs: alternating GC / GU repeats (every other diagonal fully paired), long runs."""
+    from rna_algos_amd.utils import FoldScoreSets
+    from rna_algos_amd.mccaskill_algo import Context
+    rng = np.random.default_rng(seed)
+    seqs = [np.tile(np.array([2, 1], np.uint8), 60), np.tile(np.array([2, 3], np.uint8), 45),
+            np.concatenate([np.full(40, 2, np.uint8), np.full(40, 1, np.uint8)]),
+            np.tile(np.array([0, 3, 2, 1, 1, 2], np.uint8), 30)]
+    seqs += [rng.integers(0, 4, int(n)).astype(np.uint8) for n in rng.integers(20, 220, 10)]
+    for P in (FoldScoreSets.synthetic(seed), FoldScoreSets.new(0.0)):
+        c = Context(P, device=0)
+        for contra, short in ((False, False), (True, False), (True, True)):
+            mats, logz = c.bpp_batch(seqs, contra, short)
+            for s, m, lz in zip(seqs, mats, logz):
+                ref, ref_z = O.bpp(P.ptr, s, contra, short)
+                assert np.float32(lz) == ref_z, (seed, contra, short, len(s))
+                assert_same(m.packed, ref, f"seed={seed} contra={contra} short={short} n={len(s)}")
+        c.close()
