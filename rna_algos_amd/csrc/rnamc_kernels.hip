@@ -175,20 +175,31 @@ __device__ __forceinline__ float ldu(const float* __restrict__ ubase, uint32_t l
 // fetch(buf, t) loads the operands of steps t..t+kU-1 into a register buffer,
 // compute(buf, t) folds them.  The loads of chunk c+1 are issued before chunk c is
 // folded and land in the OTHER buffer, so their latency hides under ~kU fold steps.
-template <class Buf, int U = kU, class Fetch, class Compute>
+template <class Buf, int U = kU, bool ALWAYS_FETCH = false, class Fetch, class Compute>
 __device__ __forceinline__ uint32_t pingpong(uint32_t t, uint32_t nchunks, Fetch&& fetch,
                                              Compute&& compute) {
   if (nchunks == 0) return t;
   Buf A, B;
   fetch(A, t);
   uint32_t c = 0;
+  // ALWAYS_FETCH: the next chunk is fetched unconditionally (the last iteration re-fetches
+  // its own chunk).  A conditional fetch makes the compiler's s_waitcnt placement assume
+  // the no-fetch path; which form is faster is measured per call site.
   for (;;) {
-    if (c + 1 < nchunks) fetch(B, t + U);
+    if (ALWAYS_FETCH) {
+      fetch(B, (c + 1 < nchunks) ? t + U : t);
+    } else if (c + 1 < nchunks) {
+      fetch(B, t + U);
+    }
     compute(A, t);
     t += U;
     c++;
     if (c >= nchunks) break;
-    if (c + 1 < nchunks) fetch(A, t + U);
+    if (ALWAYS_FETCH) {
+      fetch(A, (c + 1 < nchunks) ? t + U : t);
+    } else if (c + 1 < nchunks) {
+      fetch(A, t + U);
+    }
     compute(B, t);
     t += U;
     c++;
@@ -583,7 +594,7 @@ __device__ __forceinline__ void inside_sums_cell(const DeviceBatch& b, const Seq
     float re[kU], rm[kU], zz[kU], qq[kU];
   };
   // steps 1 .. d-1
-  uint32_t t = pingpong<SBuf>(
+  uint32_t t = pingpong<SBuf, kU, true>(
       1u, d >= 1 ? (d - 1) / kU : 0u,
       [&](SBuf& B, uint32_t t0) {
 #pragma unroll

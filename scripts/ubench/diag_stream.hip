@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 
 template <int W> struct __attribute__((packed, aligned(4))) Vec { float v[W]; };
 
@@ -12,12 +13,14 @@ template <int W>
 __global__ void __launch_bounds__(256) k(const float* __restrict__ a, const float* __restrict__ b,
                                          const float* __restrict__ c, float* out, uint32_t rows,
                                          uint32_t stride, uint32_t steps) {
+  extern __shared__ float lds_pad[];  // dynamic LDS only limits occupancy
+  if (steps == 0xffffffffu) out[0] = lds_pad[threadIdx.x];
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64;
   const uint32_t lane = threadIdx.x & 63;
   // each wave owns a window of the row: column offset col0 .. col0 + 64*W
   const uint32_t waves_per_row = stride / (64 * W) - 1;
   const uint32_t col0 = (wave % waves_per_row) * 64 * W;
-  const uint32_t row0 = (wave / waves_per_row) * 7919u % rows;
+  const uint32_t row0 = (uint32_t)(((uint64_t)(wave / waves_per_row) * 2654435761ull) % rows);
   float acc[W] = {0};
   for (uint32_t t0 = 0; t0 < steps; t0 += 8) {
     Vec<W> va[8], vb[8], vc[8];
@@ -41,23 +44,28 @@ __global__ void __launch_bounds__(256) k(const float* __restrict__ a, const floa
 }
 
 template <int W>
-void run(const float* a, const float* b, const float* c, float* out, uint32_t rows, uint32_t stride) {
-  const uint32_t steps = 1024;
-  const uint32_t waves = 256 * 4 * 8 * 4;  // 4 rounds of 8 waves/SIMD
+void run(const float* a, const float* b, const float* c, float* out, uint32_t rows, uint32_t stride,
+         int wps = 8, float rounds = 4.f, uint32_t steps = 1024) {
+  const uint32_t waves = (uint32_t)(256 * 4 * wps * rounds);
+  const size_t lds = wps >= 8 ? 0 : (size_t)(160 * 1024 / wps - 1024);  // blocks per CU = wps
   dim3 grid(waves / 4), block(256);
-  hipLaunchKernelGGL(k<W>, grid, block, 0, 0, a, b, c, out, rows, stride, 64);
+  hipFuncSetAttribute((const void*)k<W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(k<W>, grid, block, lds, 0, a, b, c, out, rows, stride, 64);
   hipDeviceSynchronize();
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0);
-  hipLaunchKernelGGL(k<W>, grid, block, 0, 0, a, b, c, out, rows, stride, steps);
+  hipLaunchKernelGGL(k<W>, grid, block, lds, 0, a, b, c, out, rows, stride, steps);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   double bytes = (double)waves * steps * 3 * 64 * W * 4;
-  printf("W=%d: %.2f ms, %.2f TB/s (%.1f GB moved)\n", W, ms, bytes / ms / 1e9, bytes / 1e9);
+  printf("W=%d wps=%d rounds=%.1f steps=%u: %.2f ms, %.2f TB/s (%.1f GB moved)\n", W, wps, rounds, steps, ms,
+         bytes / ms / 1e9, bytes / 1e9);
 }
 
-int main() {
-  const uint32_t stride = 2048 + 64, rows = 400000;  // 3.4 GB per array
+int main(int argc, char** argv) {
+  const uint32_t stride = 2048 + 64;
+  const uint32_t rows = argc > 1 ? atoi(argv[1]) : 400000;  // 400000 -> 3.4 GB per array
+  printf("rows=%u: %.1f GB per array\n", rows, (double)rows * stride * 4 / 1e9);
   float *a, *b, *c, *out;
   size_t n = (size_t)rows * stride + 4096;
   hipMalloc(&a, n * 4); hipMalloc(&b, n * 4); hipMalloc(&c, n * 4); hipMalloc(&out, 4 * 256 * 4 * 8 * 4 * 64);
@@ -65,6 +73,8 @@ int main() {
   run<1>(a, b, c, out, rows, stride);
   run<2>(a, b, c, out, rows, stride);
   run<4>(a, b, c, out, rows, stride);
-  run<1>(a, b, c, out, rows, stride);
+  for (int wps : {2, 4, 5, 8}) run<1>(a, b, c, out, rows, stride, wps, 4.f);
+  for (float r : {1.0f, 1.6f, 2.0f}) run<1>(a, b, c, out, rows, stride, 5, r);
+  for (uint32_t st : {256u, 512u}) run<1>(a, b, c, out, rows, stride, 5, 1.6f, st);
   return 0;
 }
