@@ -623,11 +623,125 @@ __device__ __forceinline__ void inside_sums_cell(const DeviceBatch& b, const Seq
   if (i >= 1) q.m[M_Q1C][col_off(i + d) + i - 1] = s1;  // column j, shifted one row up
 }
 
+// Latency form of the folds for launches too small to fill the chip (a single long
+// sequence): the three chains of a cell run on three lanes (lanes 0-20 of a wave:
+// sums_external, 21-41: sums_1ormore, 42-62: sums_multibranch, 21 cells per wave),
+// so a k-step costs one dependent fold instead of three.  Same operations per chain
+// as inside_sums_cell, bit for bit.
+constexpr uint32_t kSplitCells = 21;
+template <bool CONTRA>
+__device__ __forceinline__ void inside_sums_split(const DeviceBatch& b, const Seq& q, uint32_t d,
+                                                  uint32_t cell0, const LseTab* tab) {
+  const uint32_t n = q.n;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t chain = lane / kSplitCells;           // 0 ext, 1 s1, 2 s2, 3 idle
+  const uint32_t i = cell0 + lane % kSplitCells;
+  const bool valid = chain < 3 && i < n - d;
+  const uint32_t ii = valid ? i : 0u;                  // idle lanes shadow cell 0 (no stores)
+  const uint32_t od = tri_off(n, d) + ii;
+  const float* __restrict__ zre = q.m[M_ZRE];
+  const float* __restrict__ zrm = q.m[CONTRA ? M_ZRM : M_ZRE];
+  const float* __restrict__ z = q.m[M_Z];
+  const float* __restrict__ q1 = q.m[M_Q1D];
+  const uint32_t i4 = ii * 4u;
+
+  float zr = kNegInf;  // Turner: Zr_ext on every lane; CONTRAfold: Zr_ext on chain 0, Zr_mb on chain 1
+  float c = 0.f, mun = 0.f;
+  if (!CONTRA) {
+    const float prev = (d >= 1) ? zre[tri_off(n, d - 1) + ii] : kNegInf;
+    zr = lse(prev, q.m[M_QA][od], tab);
+    if (valid && chain == 0) q.m[M_ZRE][od] = zr;
+    c = b.params->turner.coeff_num_branches;
+  } else {
+    const rnamc_fold_score_sets& f = b.params->contra;
+    mun = f.multibranch_score_unpair;
+    // x + P + Q * cnt with (P, Q) = (ext_bp, ext_unpair) on chain 0, (mb_bp, mb_unpair) on chain 1
+    const float P = (chain == 0) ? f.external_score_basepair : f.multibranch_score_basepair;
+    const float Q = (chain == 0) ? f.external_score_unpair : mun;
+    const bool live = valid && chain < 2;
+    const float* __restrict__ qa = q.m[M_QA];
+    struct ABuf {
+      float xs[kU];
+    };
+    uint32_t t = pingpong<ABuf>(
+        1u, d / kU,
+        [&](ABuf& B, uint32_t t0) {
+#pragma unroll
+          for (int u = 0; u < kU; u++) B.xs[u] = ldu(qa + tri_off(n, t0 + u), i4);
+        },
+        [&](const ABuf& B, uint32_t t0) {
+#pragma unroll
+          for (int u = 0; u < kU; u++) {
+            const float x = live ? B.xs[u] : kNegInf;
+            zr = lse(zr, x + P + Q * static_cast<float>(d - t0 - u), tab);
+          }
+        });
+    for (; t <= d; t++) {
+      const float x = live ? qa[tri_off(n, t) + ii] : kNegInf;
+      zr = lse(zr, x + P + Q * static_cast<float>(d - t), tab);
+    }
+    if (valid && chain == 0) q.m[M_ZRE][od] = zr;
+    if (valid && chain == 1) q.m[M_ZRM][od] = zr;
+  }
+
+  // chain accumulators
+  float acc;
+  if (chain == 0) {
+    acc = CONTRA ? lse(b.params->contra.external_score_unpair * static_cast<float>(d + 1), zr + 0.f, tab)
+                 : lse(0.f, zr + 0.f, tab);
+  } else if (chain == 1) {
+    acc = CONTRA ? zr : zr + c;
+  } else {
+    acc = kNegInf;
+  }
+  // operands per lane: ra = Zr (ext flavour on chain 0, mb flavour otherwise under
+  // CONTRAfold), rb = Z on chain 0, Q1 otherwise
+  const float* __restrict__ pa = (CONTRA && chain != 0) ? zrm : zre;
+  const float* __restrict__ pb = (chain == 0) ? z : q1;
+  auto step = [&](float ra, float rb, uint32_t t) {
+    const float x1 = CONTRA ? ra + mun * static_cast<float>(t) : ra + c;
+    float term;
+    if (!CONTRA) {
+      term = (chain == 0) ? ra + rb : (chain == 1 ? x1 : rb + x1);
+    } else {
+      term = (chain == 1) ? x1 : rb + ra;
+    }
+    acc = lse(acc, term, tab);
+  };
+  struct SBuf {
+    float ra[kU], rb[kU];
+  };
+  uint32_t t = pingpong<SBuf>(
+      1u, d >= 1 ? (d - 1) / kU : 0u,
+      [&](SBuf& B, uint32_t t0) {
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+          B.ra[u] = pa[tri_off(n, d - t0 - u) + t0 + u + ii];
+          B.rb[u] = pb[tri_off(n, t0 + u - 1) + ii];
+        }
+      },
+      [&](const SBuf& B, uint32_t t0) {
+#pragma unroll
+        for (int u = 0; u < kU; u++) step(B.ra[u], B.rb[u], t0 + u);
+      });
+  for (; t < d; t++) step(pa[tri_off(n, d - t) + t + ii], pb[tri_off(n, t - 1) + ii], t);
+  // gather the three chains of a cell onto its chain-0 lane
+  const float s1 = __shfl(acc, static_cast<int>((lane % kSplitCells) + kSplitCells));
+  const float s2 = __shfl(acc, static_cast<int>((lane % kSplitCells) + 2 * kSplitCells));
+  if (valid && chain == 0) {
+    q.m[M_Z][od] = acc;
+    q.m[M_QM][od] = s2;
+    const float q1v = lse(s1, s2, tab);
+    q.m[M_Q1D][od] = q1v;
+    if (i >= 1) q.m[M_Q1C][col_off(i + d) + i - 1] = q1v;
+  }
+}
+
 // One launch of the inside sweep: blocks [0, blocks_sums) fold diagonal d, the
 // remaining blocks evaluate the closing-pair block of diagonal d+1, which needs
 // nothing newer than diagonal d-1 (sums_multibranch[i+1][j-1], sums_close of
 // spans <= d-1) and so runs beside the folds.
-template <bool CONTRA>
+template <bool CONTRA, bool SPLIT>
 __global__ void __launch_bounds__(256) k_inside(DeviceBatch b, uint32_t d, uint32_t blocks_sums,
                                                 uint32_t nseq, int do_sums, int do_pair) {
   __shared__ LseTab tabs;
@@ -643,9 +757,16 @@ __global__ void __launch_bounds__(256) k_inside(DeviceBatch b, uint32_t d, uint3
   const uint32_t n = q.n;
   if (bxr < blocks_sums) {
     if (!do_sums || d >= n) return;
-    const uint32_t i = bxr * blockDim.x + threadIdx.x;
-    if (i >= n - d) return;
-    inside_sums_cell<CONTRA>(b, q, d, i, tab);
+    if (SPLIT) {
+      const uint32_t wave = (bxr * blockDim.x + threadIdx.x) >> 6;
+      const uint32_t cell0 = wave * kSplitCells;
+      if (cell0 >= n - d) return;  // whole wave past the diagonal
+      inside_sums_split<CONTRA>(b, q, d, cell0, tab);
+    } else {
+      const uint32_t i = bxr * blockDim.x + threadIdx.x;
+      if (i >= n - d) return;
+      inside_sums_cell<CONTRA>(b, q, d, i, tab);
+    }
   } else {
     const uint32_t dp = d + 1;
     if (!do_pair || dp >= n) return;  // uniform over the block
@@ -941,16 +1062,27 @@ void launch_inside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n
                    uint32_t block, bool do_sums, bool do_pair, hipStream_t st) {
   const uint32_t cells_s = (do_sums && d < max_n) ? max_n - d : 0;
   const uint32_t cells_p = (do_pair && d + 1 < max_n) ? max_n - d - 1 : 0;
-  const uint32_t bs = (cells_s + block - 1) / block;
+  // launches that cannot give every SIMD a wave are latency-bound: spread the three
+  // chains of a cell over three lanes (21 cells per wave)
+  const bool split = static_cast<uint64_t>(cells_s) * nseq < 64ull * 1024ull;
+  const uint32_t cells_per_block = split ? (block / 64) * kSplitCells : block;
+  const uint32_t bs = (cells_s + cells_per_block - 1) / cells_per_block;
   const uint32_t bp = (cells_p + block - 1) / block;
   if (bs + bp == 0 || nseq == 0) return;
   const dim3 g((bs + bp) * nseq, 1, 1);
+  const int ds = do_sums ? 1 : 0, dp = do_pair ? 1 : 0;
   if (contra) {
-    hipLaunchKernelGGL(k_inside<true>, g, dim3(block), 0, st, b, d, bs, nseq, do_sums ? 1 : 0,
-                       do_pair ? 1 : 0);
+    if (split) {
+      hipLaunchKernelGGL((k_inside<true, true>), g, dim3(block), 0, st, b, d, bs, nseq, ds, dp);
+    } else {
+      hipLaunchKernelGGL((k_inside<true, false>), g, dim3(block), 0, st, b, d, bs, nseq, ds, dp);
+    }
   } else {
-    hipLaunchKernelGGL(k_inside<false>, g, dim3(block), 0, st, b, d, bs, nseq, do_sums ? 1 : 0,
-                       do_pair ? 1 : 0);
+    if (split) {
+      hipLaunchKernelGGL((k_inside<false, true>), g, dim3(block), 0, st, b, d, bs, nseq, ds, dp);
+    } else {
+      hipLaunchKernelGGL((k_inside<false, false>), g, dim3(block), 0, st, b, d, bs, nseq, ds, dp);
+    }
   }
 }
 

@@ -16,7 +16,7 @@ __constant__ float kCoef[9][4] = {
     {-0.000196278f, 0.0046084408f, 0.9634432f, 0.09831489f}, {-0.0000113994f, 0.0003734731f, 0.9959107f, 0.0149855051f},
     {0.f, 0.f, 1.f, 0.f}};
 __constant__ float kBreaks[8] = {0.66153675f, 1.6320158f, 2.4912589f, 3.3792500f, 4.426169f, 5.789071f, 7.8162727f, 11.862479f};
-struct Tab { float4 coef[9]; float2 cell[42]; };
+struct Tab { float4 coef[9]; float2 cell[42]; float4 fused[42][3]; };
 __device__ void load_tab(Tab* t) {
   unsigned x = threadIdx.x;
   if (x < 9) t->coef[x] = make_float4(kCoef[x][0], kCoef[x][1], kCoef[x][2], kCoef[x][3]);
@@ -27,6 +27,10 @@ __device__ void load_tab(Tab* t) {
     int piece = 0; for (int k = 0; k < 8; k++) piece += lo >= kBreaks[k];
     float thr = __builtin_inff(); if (piece < 8 && kBreaks[piece] < hi) thr = kBreaks[piece];
     t->cell[x] = make_float2(thr, __uint_as_float(piece * 16u));
+    int hi_piece = piece < 8 ? piece + 1 : 8;
+    t->fused[x][0] = make_float4(thr, 0.f, 0.f, 0.f);
+    t->fused[x][1] = make_float4(kCoef[piece][0], kCoef[piece][1], kCoef[piece][2], kCoef[piece][3]);
+    t->fused[x][2] = make_float4(kCoef[hi_piece][0], kCoef[hi_piece][1], kCoef[hi_piece][2], kCoef[hi_piece][3]);
   }
   __syncthreads();
 }
@@ -50,6 +54,20 @@ __device__ __forceinline__ float lseB(float sum, float x, const Tab* tab) {
   float4 co = *(const float4*)((const char*)tab + boff);
   float r = ((co.x * z + co.y) * z + co.z) * z + co.w;
   r = (z >= 11.862479f) ? z : r;
+  r = lo + r;
+  return lo == kNegInf ? hi : r;
+}
+// D: one LDS round trip: cell entry = {thr, coefs below, coefs above}
+__device__ __forceinline__ float lseD(float sum, float x, const Tab* tab) {
+  float hi = vmax(sum, x), lo = vmin(sum, x), z = hi - lo;
+  int e = (int)(__float_as_uint(z) >> 20);
+  int cell = min(max(e, 0x3EF), 0x418) - 0x3EF;
+  const float4* f = tab->fused[cell];
+  float thr = f[0].x;
+  float4 a = f[1], b = f[2];
+  bool up = z >= thr;
+  float c0 = up ? b.x : a.x, c1 = up ? b.y : a.y, c2 = up ? b.z : a.z, c3 = up ? b.w : a.w;
+  float r = ((c0 * z + c1) * z + c2) * z + c3;
   r = lo + r;
   return lo == kNegInf ? hi : r;
 }
@@ -88,6 +106,7 @@ __global__ void __launch_bounds__(64) k(float* out, unsigned long long* cyc, int
         if (V == 0) s[c] = lseA(s[c], xx, &tab);
         if (V == 1) s[c] = lseB(s[c], xx, &tab);
         if (V == 2) s[c] = lseC(s[c], xx, &tab);
+        if (V == 3) s[c] = lseD(s[c], xx, &tab);
       }
     }
     x += 0.001f;
@@ -124,6 +143,8 @@ int main() {
   run<0, 1>("A cell-LUT        1 chain");
   run<1, 1>("B ladder+LDS coef 1 chain");
   run<2, 1>("C all-VALU        1 chain");
+  run<3, 1>("D fused cell entry 1 chain");
+  run<3, 3>("D fused cell entry 3 chains");
   run<0, 2>("A cell-LUT        2 chains");
   run<1, 2>("B ladder+LDS coef 2 chains");
   run<2, 2>("C all-VALU        2 chains");
