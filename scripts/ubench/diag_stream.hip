@@ -12,7 +12,7 @@ template <int W> struct __attribute__((packed, aligned(4))) Vec { float v[W]; };
 template <int W>
 __global__ void __launch_bounds__(256) k(const float* __restrict__ a, const float* __restrict__ b,
                                          const float* __restrict__ c, float* out, uint32_t rows,
-                                         uint32_t stride, uint32_t steps) {
+                                         uint32_t stride, uint32_t steps, uint32_t misalign_bc) {
   extern __shared__ float lds_pad[];  // dynamic LDS only limits occupancy
   if (steps == 0xffffffffu) out[0] = lds_pad[threadIdx.x];
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64;
@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(256) k(const float* __restrict__ a, const floa
     for (int u = 0; u < 8; u++) {
       const uint32_t t = t0 + u;
       const size_t ra = (size_t)((row0 + rows - t % rows) % rows) * stride + col0 + (t & 31) + lane * W;
-      const size_t rb = (size_t)((row0 + t) % rows) * stride + col0 + lane * W;
+      const size_t rb = (size_t)((row0 + t) % rows) * stride + col0 + lane * W + misalign_bc * ((t * 7) & 31);
       va[u] = *reinterpret_cast<const Vec<W>*>(a + ra);
       vb[u] = *reinterpret_cast<const Vec<W>*>(b + rb);
       vc[u] = *reinterpret_cast<const Vec<W>*>(c + rb);
@@ -43,6 +43,7 @@ __global__ void __launch_bounds__(256) k(const float* __restrict__ a, const floa
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+static uint32_t g_mis = 0;
 template <int W>
 void run(const float* a, const float* b, const float* c, float* out, uint32_t rows, uint32_t stride,
          int wps = 8, float rounds = 4.f, uint32_t steps = 1024) {
@@ -50,11 +51,11 @@ void run(const float* a, const float* b, const float* c, float* out, uint32_t ro
   const size_t lds = wps >= 8 ? 0 : (size_t)(160 * 1024 / wps - 1024);  // blocks per CU = wps
   dim3 grid(waves / 4), block(256);
   hipFuncSetAttribute((const void*)k<W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(k<W>, grid, block, lds, 0, a, b, c, out, rows, stride, 64);
+  hipLaunchKernelGGL(k<W>, grid, block, lds, 0, a, b, c, out, rows, stride, 64, g_mis);
   hipDeviceSynchronize();
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0);
-  hipLaunchKernelGGL(k<W>, grid, block, lds, 0, a, b, c, out, rows, stride, steps);
+  hipLaunchKernelGGL(k<W>, grid, block, lds, 0, a, b, c, out, rows, stride, steps, g_mis);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   double bytes = (double)waves * steps * 3 * 64 * W * 4;
@@ -73,6 +74,9 @@ int main(int argc, char** argv) {
   run<1>(a, b, c, out, rows, stride);
   run<2>(a, b, c, out, rows, stride);
   run<4>(a, b, c, out, rows, stride);
+  g_mis = 1; printf("all three streams misaligned:\n");
+  run<1>(a, b, c, out, rows, stride); run<1>(a, b, c, out, rows, stride, 5, 1.6f);
+  g_mis = 0; printf("two of three aligned:\n");
   for (int wps : {2, 4, 5, 8}) run<1>(a, b, c, out, rows, stride, wps, 4.f);
   for (float r : {1.0f, 1.6f, 2.0f}) run<1>(a, b, c, out, rows, stride, 5, r);
   for (uint32_t st : {256u, 512u}) run<1>(a, b, c, out, rows, stride, 5, 1.6f, st);
