@@ -478,15 +478,19 @@ int rnamc_debug_fetch(rnamc_ctx* c, uint32_t seq_idx, int which, float* out_nxn)
   HIPCHK(hipDeviceSynchronize());
   const uint32_t n = sd->n;
   std::vector<float> packed(sd->tri_pad);  // column-major slots are a little larger than tri
-  HIPCHK(hipMemcpy(packed.data(), c->d_ws + sd->ws_off + static_cast<uint64_t>(kMat[which]) * sd->tri_pad,
-                   static_cast<size_t>(sd->tri_pad) * sizeof(float), hipMemcpyDeviceToHost));
+  // probs_multibranch{,2} live interleaved ({pm, pm2} per cell) in the two adjacent slots
+  const uint64_t slot = row_major ? static_cast<uint64_t>(M_PM) : static_cast<uint64_t>(kMat[which]);
+  const size_t count = static_cast<size_t>(sd->tri_pad) * (row_major ? 2 : 1);
+  packed.resize(count);
+  HIPCHK(hipMemcpy(packed.data(), c->d_ws + sd->ws_off + slot * sd->tri_pad, count * sizeof(float),
+                   hipMemcpyDeviceToHost));
   const float nan = std::numeric_limits<float>::quiet_NaN();
   for (uint64_t x = 0; x < static_cast<uint64_t>(n) * n; x++) out_nxn[x] = nan;
   for (uint32_t i = 0; i < n; i++)
     for (uint32_t j = i; j < n; j++) {
       const uint64_t d = j - i;
       const uint64_t cm = j >> 4, cr = j & 15u;
-      const uint64_t idx = row_major ? (16ull * (cm + 1ull) * (8ull * cm + cr) + i)  // column-major
+      const uint64_t idx = row_major ? 2ull * (16ull * (cm + 1ull) * (8ull * cm + cr) + i) + (which == 6 ? 1 : 0)
                                      : (d * n - d * (d - 1ull) / 2ull + i);
       out_nxn[static_cast<uint64_t>(i) * n + j] = packed[idx];
     }

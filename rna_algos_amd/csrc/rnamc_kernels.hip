@@ -42,7 +42,6 @@ namespace {
 
 constexpr float kNegInf = -__builtin_inff();
 constexpr int kU = RNAMC_KU;  // k-steps fetched ahead per lane
-constexpr int kUE = RNAMC_KUE;  // same, multibranch half of the pair probabilities
 
 // ----------------------------------------------------------------------------
 // numerics: src/utils.rs:579-655
@@ -842,9 +841,9 @@ __device__ __forceinline__ void outside_mb_cell(const DeviceBatch& b, const Seq&
   for (; t <= cnt_wave; t++)
     step(ldu(w + tri_off(n, d + t), i4), ldu(q1d + tri_off(n, t - 2) + d + 1, i4), t);
   if (valid) {
-    const uint32_t ocol = col_off(j) + i;
-    q.m[M_PM][ocol] = pm;
-    q.m[M_PM2][ocol] = pm2;
+    // {probs_multibranch, probs_multibranch2} interleaved: 16 k-steps of a column = one
+    // 128-byte line (slots PM and PM2 are adjacent and form one float2 array)
+    reinterpret_cast<float2*>(q.m[M_PM])[col_off(j) + i] = make_float2(pm, pm2);
   }
 }
 
@@ -916,8 +915,9 @@ __device__ __forceinline__ void outside_pair_tail(const DeviceBatch& b, const Se
   //   k+2 <= iend: the interval [k+1, i-1] is not empty
   const uint32_t iend = paired ? i : 0u;
   const uint32_t j = i + d;
-  const float4* __restrict__ ycol = reinterpret_cast<const float4*>(q.m[M_PM] + col_off(j));
-  const float4* __restrict__ y2col = reinterpret_cast<const float4*>(q.m[M_PM2] + col_off(j));
+  // {y, y2} pairs of column j: float4 = two k-steps
+  const float4* __restrict__ yycol =
+      reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(q.m[M_PM]) + col_off(j));
   const float4* __restrict__ xcol =
       reinterpret_cast<const float4*>(q.m[M_Q1C] + col_off(i >= 1 ? i - 1 : 0));
   auto step = [&](float x, float y, float y2, uint32_t k) {
@@ -933,31 +933,55 @@ __device__ __forceinline__ void outside_pair_tail(const DeviceBatch& b, const Se
     }
     p = lse(p, sa + x + y, tab);
   };
-  static_assert(kUE % 4 == 0, "column walks move whole float4");
-  struct EBuf {
-    float4 xs[kUE / 4], ys[kUE / 4], y2s[kUE / 4];
-  };
-  // steps 0 .. imax_wave-1, whole chunks (the padding covers the last partial chunk)
+  // Chunks of 16 k-steps.  A 128-byte line holds 16 steps of {y, y2} but 32 steps of x,
+  // so x is fetched for TWO chunks at a time (a line fetched in halves, microseconds
+  // apart, is usually evicted in between and read twice from HBM).  Buffers: even chunks
+  // use (xa, ya), odd chunks (xb, yb); xbn receives the odd half of the next pair.
   if (b.debug & 32) imax_wave = 0;
-  pingpong<EBuf, kUE>(
-      0u, (imax_wave + kUE - 1) / kUE,
-      [&](EBuf& B, uint32_t k0) {
+  const uint32_t nch = (imax_wave + 15u) / 16u;
+  if (nch) {
+    float4 xa[4], xb[4], xbn[4], ya[8], yb[8];
+    auto ld_x32 = [&](uint32_t k0, float4(&lo)[4], float4(&hi)[4]) {
 #pragma unroll
-        for (int u = 0; u < kUE / 4; u++) {
-          B.xs[u] = xcol[k0 / 4 + u];
-          B.ys[u] = ycol[k0 / 4 + u];
-          B.y2s[u] = y2col[k0 / 4 + u];
-        }
-      },
-      [&](const EBuf& B, uint32_t k0) {
+      for (int u = 0; u < 4; u++) {
+        lo[u] = xcol[k0 / 4 + u];
+        hi[u] = xcol[k0 / 4 + 4 + u];
+      }
+    };
+    auto ld_y16 = [&](uint32_t k0, float4(&y)[8]) {
 #pragma unroll
-        for (int u = 0; u < kUE / 4; u++) {
-          step(B.xs[u].x, B.ys[u].x, B.y2s[u].x, k0 + 4 * u);
-          step(B.xs[u].y, B.ys[u].y, B.y2s[u].y, k0 + 4 * u + 1);
-          step(B.xs[u].z, B.ys[u].z, B.y2s[u].z, k0 + 4 * u + 2);
-          step(B.xs[u].w, B.ys[u].w, B.y2s[u].w, k0 + 4 * u + 3);
-        }
-      });
+      for (int u = 0; u < 8; u++) y[u] = yycol[k0 / 2 + u];
+    };
+    auto fold16 = [&](const float4(&x)[4], const float4(&y)[8], uint32_t k0) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        step(x[u].x, y[2 * u].x, y[2 * u].y, k0 + 4 * u);
+        step(x[u].y, y[2 * u].z, y[2 * u].w, k0 + 4 * u + 1);
+        step(x[u].z, y[2 * u + 1].x, y[2 * u + 1].y, k0 + 4 * u + 2);
+        step(x[u].w, y[2 * u + 1].z, y[2 * u + 1].w, k0 + 4 * u + 3);
+      }
+    };
+    ld_x32(0, xa, xb);
+    ld_y16(0, ya);
+    uint32_t c = 0, k = 0;
+    for (;;) {
+      if (c + 1 < nch) ld_y16(k + 16, yb);
+      fold16(xa, ya, k);
+      k += 16;
+      c++;
+      if (c >= nch) break;
+      if (c + 1 < nch) {
+        ld_x32(k + 16, xa, xbn);
+        ld_y16(k + 16, ya);
+      }
+      fold16(xb, yb, k);
+      k += 16;
+      c++;
+      if (c >= nch) break;
+#pragma unroll
+      for (int u = 0; u < 4; u++) xb[u] = xbn[u];
+    }
+  }
   if (paired && p > kNegInf) {
     q.m[M_P][od] = p;
     q.m[M_W][od] = p + q.m[M_MBC][od] - qb_ij;
