@@ -38,6 +38,29 @@ extern "C" {
     out_offsets: *const u64,
     log_partition: *mut f32,
   ) -> c_int;
+  fn rnamc_fold_scores(
+    ctx: *mut RnamcCtx,
+    bases: *const u8,
+    n: u32,
+    uses_contra_model: c_int,
+    allows_short_hairpins: c_int,
+    hairpin_scores: *mut f32,
+    multibranch_close_scores: *mut f32,
+    accessible_scores: *mut f32,
+    twoloop_scores: *mut TwoloopScore,
+    twoloop_cap: u64,
+    twoloop_count: *mut u64,
+  ) -> c_int;
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct TwoloopScore {
+  i: u32,
+  j: u32,
+  k: u32,
+  l: u32,
+  score: f32,
 }
 
 struct Ctx(*mut RnamcCtx);
@@ -103,7 +126,57 @@ where
       }
     }
   }
-  // FoldScores<T>: no in-crate caller reads it (src/bin/*.rs take `.0`); callers that do
-  // (downstream crates) keep calling the crate's own get_fold_sums*, which still fills it.
-  (basepair_probs, FoldScores::<T>::new())
+  // FoldScores<T>: no in-crate caller reads it (src/bin/*.rs take `.0`), so it is filled
+  // only when the crate is built with feature "fold-scores" (downstream crates that read it).
+  let fold_scores = if cfg!(feature = "fold-scores") {
+    get_fold_scores::<T>(&bases, uses_contra_model, allows_short_hairpins, fold_score_sets)
+  } else {
+    FoldScores::<T>::new()
+  };
+  (basepair_probs, fold_scores)
+}
+
+// The four maps of src/mccaskill_algo.rs:14-19 through rnamc_fold_scores: three packed
+// triangles (NaN = key absent) and the list of twoloop_scores inserts.
+fn get_fold_scores<T: HashIndex>(
+  bases: &[u8],
+  uses_contra_model: bool,
+  allows_short_hairpins: bool,
+  fold_score_sets: &FoldScoreSets,
+) -> FoldScores<T> {
+  let n = bases.len();
+  let len = unsafe { rnamc_bpp_len(n as u32) } as usize;
+  let (mut hp, mut mb, mut ac) = (vec![0f32; len], vec![0f32; len], vec![0f32; len]);
+  let ctx = context(fold_score_sets).0;
+  let (c, s) = (uses_contra_model as c_int, allows_short_hairpins as c_int);
+  let mut count = 0u64;
+  let p = bases.as_ptr();
+  unsafe {
+    let st = rnamc_fold_scores(ctx, p, n as u32, c, s, hp.as_mut_ptr(), mb.as_mut_ptr(),
+      ac.as_mut_ptr(), std::ptr::null_mut(), 0, &mut count);
+    assert_eq!(st, 0);
+  }
+  let mut tl = vec![TwoloopScore::default(); count as usize];
+  unsafe {
+    let st = rnamc_fold_scores(ctx, p, n as u32, c, s, std::ptr::null_mut(), std::ptr::null_mut(),
+      std::ptr::null_mut(), tl.as_mut_ptr(), count, &mut count);
+    assert_eq!(st, 0);
+  }
+  let mut out = FoldScores::<T>::new();
+  let t = |x: usize| T::from_usize(x).unwrap();
+  let mut x = 0;
+  for d in 0..n {
+    for i in 0..n - d {
+      let key = (t(i), t(i + d));
+      if !hp[x].is_nan() { out.hairpin_scores.insert(key, hp[x]); }
+      if !mb[x].is_nan() { out.multibranch_close_scores.insert(key, mb[x]); }
+      if !ac[x].is_nan() { out.accessible_scores.insert(key, ac[x]); }
+      x += 1;
+    }
+  }
+  for e in tl.iter() {
+    let key = (t(e.i as usize), t(e.j as usize), t(e.k as usize), t(e.l as usize));
+    out.twoloop_scores.insert(key, e.score);
+  }
+  out
 }

@@ -95,8 +95,12 @@ struct FoldScoreSets {
   rnamc_turner_scores& turner() { return p->turner; }
 };
 
-// FoldScores<T>, src/mccaskill_algo.rs:13-19 — side products no in-crate caller reads;
-// the GPU path does not materialise them (out of scope this round).
+// FoldScores<T>, src/mccaskill_algo.rs:13-19 — side products no in-crate caller reads, so
+// mccaskill_algo leaves them empty unless asked (with_fold_scores); fold_scores<T> fills
+// them through rnamc_fold_scores.  twoloop_scores is keyed by quad_key(i,j,k,l).
+inline uint64_t quad_key(uint64_t i, uint64_t j, uint64_t k, uint64_t l) {
+  return (i << 48) | (j << 32) | (k << 16) | l;
+}
 template <class T>
 struct FoldScores {
   SparseScoreMat<T> hairpin_scores;
@@ -130,11 +134,41 @@ SparseProbMat<T> unpack(const float* packed, uint32_t n) {
   return m;
 }
 
+// the four maps the reference's inside pass fills (src/mccaskill_algo.rs:302-304, 320,
+// 333-338 / 407-409, 431, 457-462)
+template <class T>
+FoldScores<T> fold_scores(const Context& ctx, const Seq& seq, bool uses_contra_model,
+                          bool allows_short_hairpins) {
+  const uint32_t n = static_cast<uint32_t>(seq.size());
+  const uint64_t len = rnamc_bpp_len(n);
+  std::vector<float> hp(len ? len : 1), mb(hp.size()), ac(hp.size());
+  uint64_t count = 0;
+  check(rnamc_fold_scores(ctx.get(), seq.data(), n, uses_contra_model, allows_short_hairpins,
+                          hp.data(), mb.data(), ac.data(), nullptr, 0, &count));
+  std::vector<rnamc_twoloop_score> tl(count ? count : 1);
+  check(rnamc_fold_scores(ctx.get(), seq.data(), n, uses_contra_model, allows_short_hairpins,
+                          nullptr, nullptr, nullptr, tl.data(), count, &count));
+  FoldScores<T> out;
+  uint64_t x = 0;
+  for (uint32_t d = 0; d < n; d++)
+    for (uint32_t i = 0; i + d < n; i++, x++) {
+      const PosPair<T> key{static_cast<T>(i), static_cast<T>(i + d)};
+      if (hp[x] == hp[x]) out.hairpin_scores.emplace(key, hp[x]);
+      if (mb[x] == mb[x]) out.multibranch_close_scores.emplace(key, mb[x]);
+      if (ac[x] == ac[x]) out.accessible_scores.emplace(key, ac[x]);
+    }
+  out.twoloop_scores.reserve(count);
+  for (uint64_t e = 0; e < count; e++)
+    out.twoloop_scores.emplace(quad_key(tl[e].i, tl[e].j, tl[e].k, tl[e].l), tl[e].score);
+  return out;
+}
+
 // mccaskill_algo, src/mccaskill_algo.rs:247-280
 template <class T>
 std::pair<SparseProbMat<T>, FoldScores<T>> mccaskill_algo(const Context& ctx, const Seq& seq,
                                                           bool uses_contra_model,
-                                                          bool allows_short_hairpins) {
+                                                          bool allows_short_hairpins,
+                                                          bool with_fold_scores = false) {
   const uint32_t n = static_cast<uint32_t>(seq.size());
   const uint64_t offsets[2] = {0, n};
   const uint64_t out_offsets[2] = {0, rnamc_bpp_len(n)};
@@ -142,7 +176,9 @@ std::pair<SparseProbMat<T>, FoldScores<T>> mccaskill_algo(const Context& ctx, co
   float logz = 0.f;
   check(rnamc_bpp_batch(ctx.get(), 1, seq.data(), offsets, uses_contra_model, allows_short_hairpins,
                         packed.data(), out_offsets, &logz));
-  return {unpack<T>(packed.data(), n), FoldScores<T>()};
+  return {unpack<T>(packed.data(), n),
+          with_fold_scores ? fold_scores<T>(ctx, seq, uses_contra_model, allows_short_hairpins)
+                           : FoldScores<T>()};
 }
 
 // the whole FASTA at once (what src/bin/mccaskill_algo.rs:64-93 does on a thread pool)

@@ -250,6 +250,30 @@ int rnamc_ctx_last_stats(rnamc_ctx* ctx, rnamc_batch_stats* out);
 int rnamc_debug_fetch(rnamc_ctx* ctx, uint32_t seq_idx, int which, float* out_nxn);
 
 /* ------------------------------------------------------------------------- */
+/* FoldScores<T>, the second element of mccaskill_algo's result
+ * (src/mccaskill_algo.rs:14-19): the loop scores the inside pass looked up, keyed like
+ * its hash maps.  The key sets depend on the DP (a pair is a key of
+ * multibranch_close_scores / accessible_scores iff its sums_close is finite, :333-338 /
+ * :457-462; (i,j,k,l) is a key of twoloop_scores iff (k,l) has a sums_close entry, :318-320
+ * / :429-431), so the call runs the device sweep for the sequence, reads the sums_close
+ * key set back and scores on the host with the functions the kernels use.
+ *   hairpin_scores, multibranch_close_scores, accessible_scores: packed triangles of
+ *     rnamc_bpp_len(n) floats (rnamc_bpp_index), NaN = key absent; each may be NULL.
+ *   twoloop_scores: up to twoloop_cap entries, closing pair (i,j) diagonal-major, then
+ *     k ascending, l descending (the reference's visiting order); *twoloop_count gets the
+ *     full count.  With twoloop_scores == NULL only the count is produced; a non-NULL
+ *     buffer that is too small gives RNAMC_ERR_INVALID_ARG (count still set). */
+typedef struct rnamc_twoloop_score {
+  uint32_t i, j, k, l; /* (i,j) closes, (k,l) is enclosed */
+  float score;
+} rnamc_twoloop_score;
+int rnamc_fold_scores(rnamc_ctx* ctx, const uint8_t* bases, uint32_t n, int uses_contra_model,
+                      int allows_short_hairpins, float* hairpin_scores,
+                      float* multibranch_close_scores, float* accessible_scores,
+                      rnamc_twoloop_score* twoloop_scores, uint64_t twoloop_cap,
+                      uint64_t* twoloop_count);
+
+/* ------------------------------------------------------------------------- */
 /* Consumers of the path's output, host side. */
 
 /* centroid_fold (src/centroid_fold.rs:25-105) driven off a packed bpp triangle

@@ -38,7 +38,30 @@ typedef struct {
   float* basepair_probs; /* log domain until the final expf map; -inf = absent */
   float* probs_multibranch;
   float* probs_multibranch2;
+  /* optional recorder of the remaining FoldScores maps (rnamc_oracle_fold_scores):
+   * dense n x n with NaN = key absent, and the list of twoloop_scores inserts */
+  float* rec_hairpin;
+  float* rec_accessible;
+  rnamc_twoloop_score* rec_twoloop;
+  size_t rec_count, rec_cap;
+  int rec_failed;
 } ostate;
+
+static void rec_twoloop(ostate* s, uint32_t i, uint32_t j, uint32_t k, uint32_t l, float y) {
+  if (!s->rec_hairpin) return;
+  if (s->rec_count == s->rec_cap) {
+    size_t cap = s->rec_cap ? s->rec_cap * 2 : 4096;
+    rnamc_twoloop_score* q = (rnamc_twoloop_score*)realloc(s->rec_twoloop, cap * sizeof(*q));
+    if (!q) {
+      s->rec_failed = 1;
+      return;
+    }
+    s->rec_twoloop = q;
+    s->rec_cap = cap;
+  }
+  rnamc_twoloop_score e = {i, j, k, l, y};
+  s->rec_twoloop[s->rec_count++] = e;
+}
 
 static float* alloc_fill(size_t count, float v) {
   float* p = (float*)malloc(count * sizeof(float));
@@ -59,6 +82,9 @@ static void ostate_free(ostate* s) {
   free(s->basepair_probs);
   free(s->probs_multibranch);
   free(s->probs_multibranch2);
+  free(s->rec_hairpin);
+  free(s->rec_accessible);
+  free(s->rec_twoloop);
   memset(s, 0, sizeof(*s));
 }
 
@@ -97,6 +123,7 @@ static void o_get_fold_sums(const rnamc_params* p, const uint8_t* seq, ostate* s
       Score sum = ONEG_INF;
       if (j - i + 1 >= RNAMC_MIN_SPAN_HAIRPIN_CLOSE && o_has_canonical_basepair(seq[i], seq[j])) {
         Score hairpin_score = o_get_hairpin_score(t, seq, i, j);
+        if (s->rec_hairpin) s->rec_hairpin[IDX(i, j)] = hairpin_score; /* :302-304 */
         o_logsumexp(&sum, hairpin_score);
         for (uint32_t k = i + 1; k < j - 1; k++) { /* range(i+1, j-1) */
           if (k - i - 1 > RNAMC_MAX_2LOOP_LEN) break;
@@ -105,6 +132,7 @@ static void o_get_fold_sums(const rnamc_params* p, const uint8_t* seq, ostate* s
             Score x = s->sums_close[IDX(k, l)];
             if (x > ONEG_INF) { /* map hit */
               Score y = o_get_2loop_score(t, seq, i, j, k, l);
+              rec_twoloop(s, i, j, k, l, y); /* :320 */
               y = x + y;
               o_logsumexp(&sum, y);
             }
@@ -115,6 +143,7 @@ static void o_get_fold_sums(const rnamc_params* p, const uint8_t* seq, ostate* s
         Score accessible_score = o_get_accessible_score(t, seq, n, i, j);
         if (sum > ONEG_INF) {
           s->multibranch_close_scores[IDX(i, j)] = multibranch_close_score;
+          if (s->rec_accessible) s->rec_accessible[IDX(i, j)] = accessible_score; /* :336-338 */
           s->sums_close[IDX(i, j)] = sum;
           s->sums_accessible[IDX(i, j)] = sum + accessible_score;
         }
@@ -161,6 +190,7 @@ static void o_get_fold_sums_contra(const rnamc_params* p, const uint8_t* seq, os
           (allows_short_hairpins || j - i + 1 >= RNAMC_MIN_SPAN_HAIRPIN_CLOSE)) {
         if (j - i - 1 <= RNAMC_MAX_LOOP_LEN) {
           Score hairpin_score = o_get_hairpin_score_contra(f, seq, i, j);
+          if (s->rec_hairpin) s->rec_hairpin[IDX(i, j)] = hairpin_score; /* :407-409 */
           o_logsumexp(&sum, hairpin_score);
         }
         /* range(i+1, j-1): empty when j < i+2; j >= i+1 here (canonical => i != j) */
@@ -171,6 +201,7 @@ static void o_get_fold_sums_contra(const rnamc_params* p, const uint8_t* seq, os
             Score x = s->sums_close[IDX(k, l)];
             if (x > ONEG_INF) {
               Score y = o_get_2loop_score_contra(f, seq, i, j, k, l);
+              rec_twoloop(s, i, j, k, l, y); /* :431 */
               y = x + y;
               o_logsumexp(&sum, y);
             }
@@ -181,6 +212,7 @@ static void o_get_fold_sums_contra(const rnamc_params* p, const uint8_t* seq, os
         Score accessible_score = o_get_accessible_score_contra(f, seq, n, i, j);
         if (sum > ONEG_INF) {
           s->multibranch_close_scores[IDX(i, j)] = multibranch_close_score;
+          if (s->rec_accessible) s->rec_accessible[IDX(i, j)] = accessible_score; /* :460-462 */
           s->sums_close[IDX(i, j)] = sum;
           s->sums_accessible[IDX(i, j)] = sum + accessible_score;
         }
@@ -401,6 +433,56 @@ int rnamc_oracle_bpp(const rnamc_params* p, const uint8_t* seq, uint32_t n, int 
   return rnamc_oracle_bpp_dump(p, seq, n, uses_contra_model, allows_short_hairpins, bpp_packed,
                                log_partition, NULL);
 }
+
+/* FoldScores<T> as the reference's inside pass leaves it (mccaskill_algo.rs:14-19; inserts
+ * at 302-304, 320, 333-338 / 407-409, 431, 457-462).  Outputs in the layout of
+ * rnamc_fold_scores (include/rnamc.h): three packed diagonal-major triangles with NaN =
+ * key absent, and the twoloop_scores inserts in the reference's own visiting order.
+ * *twoloop is malloc'ed here; release it with rnamc_oracle_free. */
+int rnamc_oracle_fold_scores(const rnamc_params* p, const uint8_t* seq, uint32_t n,
+                             int uses_contra_model, int allows_short_hairpins,
+                             float* hairpin_scores, float* multibranch_close_scores,
+                             float* accessible_scores, rnamc_twoloop_score** twoloop,
+                             uint64_t* twoloop_count) {
+  int st = check_args(p, seq, n);
+  if (st) return st;
+  ostate s;
+  st = ostate_init(&s, n);
+  if (st) return st;
+  s.rec_hairpin = alloc_fill((size_t)n * n, NAN);
+  s.rec_accessible = alloc_fill((size_t)n * n, NAN);
+  if (!s.rec_hairpin || !s.rec_accessible) {
+    ostate_free(&s);
+    return RNAMC_ERR_OOM;
+  }
+  if (uses_contra_model)
+    o_get_fold_sums_contra(p, seq, &s, allows_short_hairpins);
+  else
+    o_get_fold_sums(p, seq, &s);
+  if (s.rec_failed) {
+    ostate_free(&s);
+    return RNAMC_ERR_OOM;
+  }
+  size_t o = 0;
+  for (uint32_t d = 0; d < n; d++)
+    for (uint32_t i = 0; i + d < n; i++, o++) {
+      const size_t x = IDX(i, i + d);
+      const int member = s.sums_close[x] > ONEG_INF;
+      if (hairpin_scores) hairpin_scores[o] = s.rec_hairpin[x];
+      if (multibranch_close_scores)
+        multibranch_close_scores[o] = member ? s.multibranch_close_scores[x] : NAN;
+      if (accessible_scores) accessible_scores[o] = member ? s.rec_accessible[x] : NAN;
+    }
+  if (twoloop_count) *twoloop_count = s.rec_count;
+  if (twoloop) {
+    *twoloop = s.rec_twoloop;
+    s.rec_twoloop = NULL;
+  }
+  ostate_free(&s);
+  return RNAMC_OK;
+}
+
+void rnamc_oracle_free(void* ptr) { free(ptr); }
 
 /* ---- batch on a thread pool: one sequence per task, as the reference's
  * binaries do with scoped_threadpool (src/bin/mccaskill_algo.rs:58-93). ---- */

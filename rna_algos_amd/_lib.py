@@ -23,7 +23,7 @@ SYMBOLS = [
     "rnamc_params_save", "rnamc_params_load", "rnamc_params_field",
     "rnamc_ctx_create", "rnamc_ctx_destroy", "rnamc_ctx_set",
     "rnamc_bpp_batch", "rnamc_bpp_batch_device", "rnamc_ctx_last_stats",
-    "rnamc_debug_fetch", "rnamc_centroid_fold",
+    "rnamc_debug_fetch", "rnamc_fold_scores", "rnamc_centroid_fold",
 ]
 
 
@@ -85,6 +85,8 @@ def lib():
     L.rnamc_bpp_batch_device.argtypes = [vp, C.c_uint32, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.rnamc_ctx_last_stats.argtypes = [vp, C.POINTER(BatchStats)]
     L.rnamc_debug_fetch.argtypes = [vp, C.c_uint32, C.c_int, vp]
+    L.rnamc_fold_scores.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, vp, vp, vp, vp,
+                                    C.c_uint64, u64p]
     L.rnamc_centroid_fold.argtypes = [vp, C.c_uint32, C.c_float, vp, C.c_uint32, u32p, f32p]
     _lib = L
     return L

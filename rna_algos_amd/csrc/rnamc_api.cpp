@@ -12,12 +12,15 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <atomic>
 #include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rnamc_device.h"
+#include "rnamc_scoring.h"
 
 using namespace rnamc;
 
@@ -35,13 +38,14 @@ struct rnamc_ctx {
   rnamc_params host_params;
   rnamc_params* d_params = nullptr;
   float* d_hp_init = nullptr;
+  std::vector<float> h_hp_init;  // host copy, for rnamc_fold_scores
   uint32_t hp_init_len = 0;
   float* d_ws = nullptr;
   uint64_t ws_floats = 0;
   SeqDesc* d_seqs = nullptr;
   uint64_t seqs_cap = 0;
   hipStream_t own_stream = nullptr;
-  std::mutex mu;
+  std::recursive_mutex mu;  // rnamc_fold_scores re-enters rnamc_bpp_batch
   // knobs
   int64_t group_max_seqs = 8192;
   int64_t group_max_nt = 2ll << 20;  // a group holds ~2M nucleotides (or 64 GB of DP state)
@@ -101,6 +105,7 @@ int ensure_hp_init(rnamc_ctx* c, uint32_t max_n) {
   HIPCHK(hipMalloc(&c->d_hp_init, sizeof(float) * len));
   HIPCHK(hipMemcpy(c->d_hp_init, hp.data(), sizeof(float) * len, hipMemcpyHostToDevice));
   c->hp_init_len = len;
+  c->h_hp_init = std::move(hp);
   return RNAMC_OK;
 }
 
@@ -283,6 +288,56 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
   return RNAMC_OK;
 }
 
+// FoldScores of one sequence on the host, given the sums_close key set (packed
+// diagonal-major, finite = key present).  Work is split by closing diagonal.
+template <class Model>
+void fold_scores_host(const Model& M, bool contra, bool allows_short, const uint8_t* s, uint32_t n,
+                      const float* qb, float* hp, float* mb, float* ac, rnamc_twoloop_score* tl,
+                      const std::vector<uint64_t>* tl_begin, std::vector<uint64_t>* tl_count) {
+  const float nan = std::numeric_limits<float>::quiet_NaN();
+  const float ninf = -std::numeric_limits<float>::infinity();
+  auto tri = [n](uint32_t i, uint32_t j) {
+    const uint64_t d = j - i;
+    return d * n - d * (d - 1ull) / 2ull + i;
+  };
+  const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  std::vector<std::thread> pool;
+  std::atomic<uint32_t> next{0};
+  auto work = [&]() {
+    for (;;) {
+      const uint32_t d = next.fetch_add(1);
+      if (d >= n) return;
+      uint64_t cnt = 0;
+      uint64_t w = tl_begin ? (*tl_begin)[d] : 0;
+      for (uint32_t i = 0; i + d < n; i++) {
+        const uint32_t j = i + d;
+        const uint64_t x = tri(i, j);
+        const bool act = canonical(s[i], s[j]) &&
+                         ((contra && allows_short) || d + 1 >= RNAMC_MIN_SPAN_HAIRPIN_CLOSE);
+        if (!tl_begin) {
+          if (hp) hp[x] = (act && (!contra || d - 1 <= RNAMC_MAX_LOOP_LEN)) ? M.hairpin(s, n, i, j) : nan;
+          const bool member = act && qb[x] > ninf;
+          if (mb) mb[x] = member ? M.mbclose(s, n, i, j) : nan;
+          if (ac) ac[x] = member ? M.accessible(s, n, i, j) : nan;
+        }
+        if (!act || d < 3) continue;
+        // k in i+1 .. j-2, a = k-i-1 <= 30; l from j-1 down to k+1, a + b <= 30
+        for (uint32_t k = i + 1; k + 1 < j && k - i - 1 <= RNAMC_MAX_2LOOP_LEN; k++) {
+          for (uint32_t l = j - 1; l > k && (j - l - 1) + (k - i - 1) <= RNAMC_MAX_2LOOP_LEN; l--) {
+            if (!(qb[tri(k, l)] > ninf)) continue;
+            if (tl_begin) tl[w++] = rnamc_twoloop_score{i, j, k, l, M.twoloop(s, i, j, k, l)};
+            cnt++;
+          }
+        }
+      }
+      if (tl_count) (*tl_count)[d] = cnt;
+    }
+  };
+  for (unsigned t = 1; t < hw; t++) pool.emplace_back(work);
+  work();
+  for (auto& t : pool) t.join();
+}
+
 }  // namespace
 
 extern "C" {
@@ -352,7 +407,7 @@ void rnamc_ctx_destroy(rnamc_ctx* c) {
 
 int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
   if (!c || !name) return RNAMC_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   const std::string k(name);
   if (k == "group_max_seqs" && value >= 1) {
     c->group_max_seqs = std::min<int64_t>(value, 65535);
@@ -378,7 +433,7 @@ int rnamc_bpp_batch_device(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases
                            float* d_log_partition, void* hip_stream) {
   if (!c || !offsets || !out_offsets || (n_seqs && (!d_bases || !d_bpp)))
     return RNAMC_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   DeviceGuard guard(c->device);
   if (!guard.ok) return RNAMC_ERR_NO_DEVICE;
   return run_batch(c, n_seqs, d_bases, offsets, uses_contra_model != 0, allows_short_hairpins != 0,
@@ -398,7 +453,7 @@ int rnamc_bpp_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* bases, const u
     for (uint64_t x = offsets[s]; x < offsets[s + 1]; x++)
       if (bases[x] > 3) return RNAMC_ERR_INVALID_BASE;
   }
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   DeviceGuard guard(c->device);
   if (!guard.ok) return RNAMC_ERR_NO_DEVICE;
   // device-side packing: bases as given; bpp triangles packed back to back
@@ -456,14 +511,14 @@ int rnamc_bpp_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* bases, const u
 
 int rnamc_ctx_last_stats(rnamc_ctx* c, rnamc_batch_stats* out) {
   if (!c || !out) return RNAMC_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   *out = c->stats;
   return RNAMC_OK;
 }
 
 int rnamc_debug_fetch(rnamc_ctx* c, uint32_t seq_idx, int which, float* out_nxn) {
   if (!c || !out_nxn) return RNAMC_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   if (c->group_begin.size() < 2) return RNAMC_ERR_INVALID_ARG;
   const size_t g = c->group_begin.size() - 2;
   const SeqDesc* sd = nullptr;
@@ -494,6 +549,52 @@ int rnamc_debug_fetch(rnamc_ctx* c, uint32_t seq_idx, int which, float* out_nxn)
                                      : (d * n - d * (d - 1ull) / 2ull + i);
       out_nxn[static_cast<uint64_t>(i) * n + j] = packed[idx];
     }
+  return RNAMC_OK;
+}
+
+int rnamc_fold_scores(rnamc_ctx* c, const uint8_t* bases, uint32_t n, int uses_contra_model,
+                      int allows_short_hairpins, float* hairpin_scores,
+                      float* multibranch_close_scores, float* accessible_scores,
+                      rnamc_twoloop_score* twoloop_scores, uint64_t twoloop_cap,
+                      uint64_t* twoloop_count) {
+  if (!c || !bases) return RNAMC_ERR_INVALID_ARG;
+  if (n == 0) return RNAMC_ERR_EMPTY_SEQ;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  // the device sweep of this one sequence leaves sums_close in the workspace
+  const uint64_t offsets[2] = {0, n}, out_offsets[2] = {0, 0};
+  const uint64_t tri_len = rnamc_bpp_len(n);
+  std::vector<float> bpp(tri_len);
+  int rc = rnamc_bpp_batch(c, 1, bases, offsets, uses_contra_model, allows_short_hairpins,
+                           bpp.data(), out_offsets, nullptr);
+  if (rc) return rc;
+  DeviceGuard guard(c->device);
+  if (!guard.ok) return RNAMC_ERR_NO_DEVICE;
+  const SeqDesc& sd = c->descs.back();
+  std::vector<float>& qb = bpp;  // sums_close, packed diagonal-major like the result
+  HIPCHK(hipMemcpy(qb.data(), c->d_ws + sd.ws_off + static_cast<uint64_t>(M_QB) * sd.tri_pad,
+                   tri_len * sizeof(float), hipMemcpyDeviceToHost));
+  const bool contra = uses_contra_model != 0, shorthp = allows_short_hairpins != 0;
+  std::vector<uint64_t> count(n, 0), begin(n + 1, 0);
+  const Turner MT{c->host_params.turner, c->h_hp_init.data()};
+  const Contra MC{c->host_params.contra};
+  auto pass = [&](rnamc_twoloop_score* tl, const std::vector<uint64_t>* b, std::vector<uint64_t>* k) {
+    if (contra)
+      fold_scores_host(MC, true, shorthp, bases, n, qb.data(), hairpin_scores,
+                       multibranch_close_scores, accessible_scores, tl, b, k);
+    else
+      fold_scores_host(MT, false, shorthp, bases, n, qb.data(), hairpin_scores,
+                       multibranch_close_scores, accessible_scores, tl, b, k);
+  };
+  pass(nullptr, nullptr, &count);
+  for (uint32_t d = 0; d < n; d++) begin[d + 1] = begin[d] + count[d];
+  if (twoloop_count) *twoloop_count = begin[n];
+  if (twoloop_scores) {
+    if (twoloop_cap < begin[n]) {
+      set_last_error("rnamc_fold_scores: twoloop_cap is smaller than the entry count");
+      return RNAMC_ERR_INVALID_ARG;
+    }
+    pass(twoloop_scores, &begin, nullptr);
+  }
   return RNAMC_OK;
 }
 

@@ -35,12 +35,12 @@
 #include <cstdint>
 
 #include "rnamc_device.h"
+#include "rnamc_scoring.h"
 
 namespace rnamc {
 
 namespace {
 
-constexpr float kNegInf = -__builtin_inff();
 constexpr int kU = RNAMC_KU;  // k-steps fetched ahead per lane
 
 // ----------------------------------------------------------------------------
@@ -222,16 +222,6 @@ __device__ __forceinline__ uint32_t col_off(uint32_t j) {
   return 16u * (m + 1u) * (8u * m + r);
 }
 
-__device__ __forceinline__ bool canonical(int a, int b) {
-  // AU CG GC GU UA UG  <=>  a+b == 3 (AU, CG) or {a,b} == {G,U}
-  return (a + b == 3) || (a + b == 5);
-}
-
-__device__ __forceinline__ bool augu(int a, int b) {
-  // AU UA GU UG: canonical and not CG/GC
-  return canonical(a, b) && !((a == 1 && b == 2) || (a == 2 && b == 1));
-}
-
 struct Seq {
   const uint8_t* s;  // base codes
   uint32_t n;
@@ -297,102 +287,6 @@ static_assert(kProbes % kPU == 0, "probe list is walked in whole chunks");
 static_assert(RNAMC_MAX_2LOOP_LEN == RNAMC_MAX_LOOP_LEN, "one probe triangle for both models");
 
 #include "rnamc_probes.h"
-
-// ----------------------------------------------------------------------------
-// Turner model scores: src/utils.rs:166-411
-
-struct Turner {
-  const rnamc_turner_scores& t;
-  const float* hp_init;  // hairpin initiation by loop length incl. extrapolation
-
-  __device__ __forceinline__ float pen(int a, int b) const {
-    return augu(a, b) ? t.helix_augu_end_penalty : 0.f;
-  }
-
-  // get_hairpin_score, src/utils.rs:166-205
-  __device__ float hairpin(const uint8_t* s, uint32_t /*n*/, uint32_t i, uint32_t j) const {
-    const uint32_t span = j - i + 1;
-    if (span <= RNAMC_MAX_SPECIAL_HAIRPIN_LEN) {
-      for (uint32_t x = 0; x < t.num_special_hairpins; x++) {
-        if (t.special_hairpin_lens[x] != span) continue;
-        bool eq = true;
-        for (uint32_t y = 0; y < span; y++) eq = eq && (t.special_hairpin_seqs[x][y] == s[i + y]);
-        if (eq) {
-          const float sc = t.special_hairpin_scores[x];
-          if (sc > kNegInf) return sc;
-          break;
-        }
-      }
-    }
-    const uint32_t len = j - i - 1;
-    const int bi = s[i], bj = s[j];
-    float hs;
-    if (len == t.min_hairpin_len) {
-      hs = hp_init[len];
-    } else {
-      hs = hp_init[len] + t.terminal_mismatch_scores_hairpin[bi][bj][s[i + 1]][s[j - 1]];
-    }
-    return hs + pen(bi, bj);
-  }
-
-  // get_multibranch_close_score, src/utils.rs:368-382
-  __device__ float mbclose(const uint8_t* s, uint32_t /*n*/, uint32_t i, uint32_t j) const {
-    const int ci = s[i], cj = s[j];
-    return t.init_multibranch_base +
-           t.terminal_mismatch_scores_multibranch[cj][ci][s[j - 1]][s[i + 1]] + pen(ci, cj);
-  }
-
-  // get_accessible_score, src/utils.rs:384-411, uses_sentinel_bases = false
-  __device__ float accessible(const uint8_t* s, uint32_t n, uint32_t i, uint32_t j) const {
-    const int ai = s[i], aj = s[j];
-    float sc;
-    if (i > 0 && j < n - 1) {
-      sc = t.terminal_mismatch_scores_multibranch[ai][aj][s[i - 1]][s[j + 1]];
-    } else if (i > 0) {
-      sc = t.dangling_scores_5prime[ai][aj][s[i - 1]];
-    } else if (j < n - 1) {
-      sc = t.dangling_scores_3prime[ai][aj][s[j + 1]];
-    } else {
-      sc = 0.f;
-    }
-    return sc + pen(ai, aj);
-  }
-};
-
-// ----------------------------------------------------------------------------
-// CONTRAfold model scores: src/utils.rs:413-556, src/mccaskill_algo.rs:437-455
-
-struct Contra {
-  const rnamc_fold_score_sets& f;
-
-  __device__ __forceinline__ float junction_single(const uint8_t* s, uint32_t y0,
-                                                   uint32_t y1) const {
-    const int a0 = s[y0], a1 = s[y1];
-    return f.helix_close_scores[a0][a1] + f.terminal_mismatch_scores[a0][a1][s[y0 + 1]][s[y1 - 1]];
-  }
-
-  __device__ __forceinline__ float junction(const uint8_t* s, uint32_t n, uint32_t p0,
-                                            uint32_t p1) const {
-    const int b0 = s[p0], b1 = s[p1];
-    return f.helix_close_scores[b0][b1] +
-           (p0 < n - 1 ? f.dangling_scores_left[b0][b1][s[p0 + 1]] : 0.f) +
-           (p1 > 0 ? f.dangling_scores_right[b0][b1][s[p1 - 1]] : 0.f);
-  }
-
-  __device__ float hairpin(const uint8_t* s, uint32_t /*n*/, uint32_t i, uint32_t j) const {
-    uint32_t len = j - i - 1;
-    if (len > RNAMC_MAX_LOOP_LEN) len = RNAMC_MAX_LOOP_LEN;
-    return f.hairpin_scores_len_cumulative[len] + junction_single(s, i, j);
-  }
-
-  __device__ float mbclose(const uint8_t* s, uint32_t n, uint32_t i, uint32_t j) const {
-    return f.multibranch_score_base + f.multibranch_score_basepair + junction(s, n, i, j);
-  }
-
-  __device__ float accessible(const uint8_t* s, uint32_t n, uint32_t i, uint32_t j) const {
-    return junction(s, n, j, i) + f.basepair_scores[s[i]][s[j]];
-  }
-};
 
 template <bool CONTRA>
 struct ModelOf;

@@ -62,16 +62,48 @@ class BppMatrix:
         return m
 
 
-class FoldScores:
-    """Placeholder of FoldScores<T> (src/mccaskill_algo.rs:13-19): the four score
-    maps are side products no in-crate caller reads; the GPU
-    path recomputes 2-loop scores on the fly and does not materialise them."""
+# one rnamc_twoloop_score (include/rnamc.h)
+TWOLOOP_DTYPE = np.dtype([("i", "<u4"), ("j", "<u4"), ("k", "<u4"), ("l", "<u4"),
+                          ("score", "<f4")])
 
-    def __init__(self):
-        self.hairpin_scores = {}
-        self.twoloop_scores = {}
-        self.multibranch_close_scores = {}
-        self.accessible_scores = {}
+
+def _sparse_scores(n, packed):
+    out = {}
+    x = 0
+    for d in range(n):
+        row = packed[x:x + n - d]
+        for i in np.nonzero(~np.isnan(row))[0]:
+            out[(int(i), int(i) + d)] = float(row[i])
+        x += n - d
+    return out
+
+
+class FoldScores:
+    """FoldScores<T> (src/mccaskill_algo.rs:13-19): hairpin_scores, twoloop_scores,
+    multibranch_close_scores, accessible_scores keyed like the reference's hash maps.
+    No in-crate caller reads them, so they are materialised on first access
+    (rnamc_fold_scores: device sweep for the key sets, host scoring)."""
+
+    def __init__(self, materialise=None):
+        self._materialise = materialise
+        self._maps = None
+
+    def _get(self, x):
+        if self._maps is None:
+            if self._materialise is None:
+                self._maps = ({}, {}, {}, {})
+            else:
+                n, hp, mb, ac, tl = self._materialise()
+                two = {(int(e["i"]), int(e["j"]), int(e["k"]), int(e["l"])): float(e["score"])
+                       for e in tl}
+                self._maps = (_sparse_scores(n, hp), two, _sparse_scores(n, mb),
+                              _sparse_scores(n, ac))
+        return self._maps[x]
+
+    hairpin_scores = property(lambda self: self._get(0))
+    twoloop_scores = property(lambda self: self._get(1))
+    multibranch_close_scores = property(lambda self: self._get(2))
+    accessible_scores = property(lambda self: self._get(3))
 
 
 class Context:
@@ -130,6 +162,23 @@ class Context:
             int(bool(allows_short_hairpins)), d_bpp_ptr, out_offsets.ctypes.data, d_logz_ptr,
             stream_ptr))
 
+    def fold_scores_packed(self, seq, uses_contra_model, allows_short_hairpins):
+        """-> (n, hairpin, multibranch_close, accessible packed triangles with NaN = key
+        absent, twoloop entries as a TWOLOOP_DTYPE array)."""
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        n = len(seq)
+        if n == 0:
+            raise _lib.RnamcError(_lib.ERR_EMPTY_SEQ)
+        hp, mb, ac = (np.empty(bpp_len(n), dtype=np.float32) for _ in range(3))
+        count = C.c_uint64(0)
+        args = (self._h, seq.ctypes.data, n, int(bool(uses_contra_model)),
+                int(bool(allows_short_hairpins)), hp.ctypes.data, mb.ctypes.data, ac.ctypes.data)
+        _lib.check(_lib.lib().rnamc_fold_scores(*args, None, 0, C.byref(count)))
+        tl = np.empty(count.value, dtype=TWOLOOP_DTYPE)
+        _lib.check(_lib.lib().rnamc_fold_scores(*args, tl.ctypes.data, count.value,
+                                                C.byref(count)))
+        return n, hp, mb, ac, tl
+
     def debug_fetch(self, seq_idx, which, n):
         out = np.empty((n, n), dtype=np.float32)
         _lib.check(_lib.lib().rnamc_debug_fetch(self._h, seq_idx, which, out.ctypes.data))
@@ -162,7 +211,10 @@ def mccaskill_algo_packed(seq, uses_contra_model, allows_short_hairpins, fold_sc
 def mccaskill_algo(seq, uses_contra_model, allows_short_hairpins, fold_score_sets):
     """(SparseProbMat, FoldScores) like the reference (src/mccaskill_algo.rs:247-280)."""
     mat, _ = mccaskill_algo_packed(seq, uses_contra_model, allows_short_hairpins, fold_score_sets)
-    return mat.sparse(), FoldScores()
+    seq = np.array(seq, dtype=np.uint8)
+    ctx = _context_for(fold_score_sets)
+    return mat.sparse(), FoldScores(
+        lambda: ctx.fold_scores_packed(seq, uses_contra_model, allows_short_hairpins))
 
 
 def mccaskill_algo_batch(seqs, uses_contra_model, allows_short_hairpins, fold_score_sets):

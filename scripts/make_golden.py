@@ -48,6 +48,21 @@ def main(which):
                 arrs[f"trna{idx}_{'contra' if contra else 'turner'}_logz"] = np.array([lz], np.float32)
         np.savez_compressed(os.path.join(GOLD, "trna_bpp_synthetic_seed1.npz"), **arrs)
         return
+    if which == "batch":
+        # sequences 0, 1, 3 of the 10k-sequence bench batch (lengths 1653, 1024, 531)
+        from rna_algos_amd import workloads as W
+        lens = W.batch_lengths(8)
+        res = {}
+        for idx in (0, 1, 3):
+            s = W.synthetic_seq(int(lens[idx]), (10000 << 32) + idx)
+            for contra in (0, 1):
+                t0 = time.time()
+                out, lz = O.bpp(P.ptr, s, contra, 0)
+                res[f"batch{idx}_{'contra' if contra else 'turner'}"] = summary(out, lz, len(s), time.time() - t0)
+        with open(os.path.join(GOLD, "checksums_batch.json"), "w") as fh:
+            json.dump({"param_seed": PARAM_SEED, "cases": res}, fh, indent=1)
+        print(json.dumps(res, indent=1))
+        return
     cases = {"n1024": [(1024, 1024, 1), (1024, 1024, 0)], "n4096_turner": [(4096, 4096, 0)],
              "n4096_contra": [(4096, 4096, 1)]}[which]
     res = {}

@@ -41,6 +41,15 @@ int main(int argc, char** argv) {
           if (a.find(pr) == a.end()) return 6;
       }
     }
+    {  // FoldScores<T>: every pair with a probability has its two per-pair scores
+      auto r = mccaskill_algo<uint8_t>(ctx, seqs[0], false, false, true);
+      const auto& fs = r.second;
+      if (fs.multibranch_close_scores.size() != r.first.size()) return 8;
+      if (fs.accessible_scores.size() != r.first.size()) return 8;
+      for (const auto& kv : r.first)
+        if (fs.accessible_scores.find(kv.first) == fs.accessible_scores.end()) return 9;
+      if (fs.hairpin_scores.size() < r.first.size() || fs.twoloop_scores.empty()) return 10;
+    }
     try {  // a byte outside ACGU: the reference panics
       bytes2seq("ACGT");
       return 7;

@@ -28,6 +28,10 @@ def lib():
         L.rnamc_oracle_bpp_batch.argtypes = [vp, C.c_uint32, vp, vp, C.c_int, C.c_int, vp, vp, vp,
                                              C.c_uint32]
         L.rnamc_oracle_bruteforce.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, vp, vp, vp]
+        L.rnamc_oracle_fold_scores.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, vp, vp, vp,
+                                               C.POINTER(vp), C.POINTER(C.c_uint64)]
+        L.rnamc_oracle_free.argtypes = [vp]
+        L.rnamc_oracle_free.restype = None
         L.rnamc_oracle_centroid_fold.argtypes = [vp, C.c_uint32, C.c_float, vp, C.c_uint32, vp, vp]
         _lib = L
     return _lib
@@ -78,6 +82,29 @@ def bpp_batch(params_ptr, seqs, contra, short=False, n_threads=1, want_bpp=True)
     if not want_bpp:
         return None, logz
     return [out[int(out_offsets[s]):int(out_offsets[s + 1])] for s in range(len(seqs))], logz
+
+
+TWOLOOP_DTYPE = np.dtype([("i", "<u4"), ("j", "<u4"), ("k", "<u4"), ("l", "<u4"),
+                          ("score", "<f4")])
+
+
+def fold_scores(params_ptr, seq, contra, short=False):
+    """-> (hairpin, multibranch_close, accessible packed triangles (NaN = key absent),
+    twoloop entries in the reference's insertion order)"""
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    n = seq.shape[0]
+    hp, mb, ac = (np.empty(n * (n + 1) // 2, dtype=np.float32) for _ in range(3))
+    ptr, count = C.c_void_p(), C.c_uint64()
+    _chk(lib().rnamc_oracle_fold_scores(params_ptr, seq.ctypes.data, n, int(contra), int(short),
+                                        hp.ctypes.data, mb.ctypes.data, ac.ctypes.data,
+                                        C.byref(ptr), C.byref(count)))
+    if count.value:
+        buf = (C.c_char * (count.value * TWOLOOP_DTYPE.itemsize)).from_address(ptr.value)
+        tl = np.frombuffer(buf, dtype=TWOLOOP_DTYPE).copy()
+    else:
+        tl = np.empty(0, dtype=TWOLOOP_DTYPE)
+    lib().rnamc_oracle_free(ptr)
+    return hp, mb, ac, tl
 
 
 def bruteforce(params_ptr, seq, contra, short=False):

@@ -350,3 +350,59 @@ def test_other_tables_and_low_complexity(built, seed):
                 assert np.float32(lz) == ref_z, (seed, contra, short, len(s))
                 assert_same(m.packed, ref, f"seed={seed} contra={contra} short={short} n={len(s)}")
         c.close()
+
+
+def test_bench_batch_members_golden(ctx, params):
+    """Sequences 0, 1, 3 of the bench's own 10k batch (lengths 1653, 1024, 531), both
+    models, against the oracle's committed checksums (scripts/make_golden.py batch)."""
+    from rna_algos_amd import workloads as W
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "checksums_batch.json")))["cases"]
+    lens = W.batch_lengths(8)
+    seqs = [W.synthetic_seq(int(lens[i]), (10000 << 32) + i) for i in (0, 1, 3)]
+    for contra, name in ((False, "turner"), (True, "contra")):
+        mats, logz = ctx.bpp_batch(seqs, contra, False)
+        for idx, m, lz in zip((0, 1, 3), mats, logz):
+            ref = g[f"batch{idx}_{name}"]
+            assert int(np.float32(lz).view(np.uint32)) == ref["log_partition_bits"]
+            a = m.packed.copy()
+            assert int((a >= -0.5).sum()) == ref["present"]
+            a[a >= 0.9999] = 1.0
+            assert hashlib.sha256(a.tobytes()).hexdigest() == ref["sha256"], (idx, name)
+
+
+@pytest.mark.parametrize("contra,short", [(False, False), (True, False), (True, True)])
+def test_fold_scores_match_reference_maps(ctx, params, trnas, contra, short):
+    """FoldScores<T> (src/mccaskill_algo.rs:14-19): the four maps from rnamc_fold_scores
+    (device sweep for the key sets, host scoring with the kernels' scorers) equal the
+    oracle's recording of the reference's inserts — same keys, same f32 bits, same order."""
+    rng = np.random.default_rng(9)
+    seqs = [trnas[1][1], rng.integers(0, 4, 130).astype(np.uint8),
+            np.array([1, 2, 1, 2, 0, 0, 0, 2, 1, 2, 1], np.uint8), np.array([3], np.uint8)]
+    for seq in seqs:
+        n, hp, mb, ac, tl = ctx.fold_scores_packed(seq, contra, short)
+        rhp, rmb, rac, rtl = O.fold_scores(params.ptr, seq, contra, short)
+        for got, ref, name in ((hp, rhp, "hairpin"), (mb, rmb, "mbclose"), (ac, rac, "accessible")):
+            assert np.array_equal(np.isnan(got), np.isnan(ref)), name
+            assert np.array_equal(got.view(np.uint32)[~np.isnan(ref)],
+                                  ref.view(np.uint32)[~np.isnan(ref)]), name
+        assert tl.shape == rtl.shape
+        assert tl.tobytes() == rtl.tobytes()
+
+
+def test_mccaskill_algo_returns_fold_scores(params, trnas):
+    """The mirror of the reference entry point returns (bpp map, FoldScores) with the maps
+    filled like the reference's (lazily, on first access)."""
+    from rna_algos_amd.mccaskill_algo import mccaskill_algo
+    seq = trnas[2][1][:48]
+    bpp, fs = mccaskill_algo(seq, False, False, params)
+    rhp, rmb, rac, rtl = O.fold_scores(params.ptr, seq, False, False)
+    n = len(seq)
+    assert set(fs.multibranch_close_scores) == set(fs.accessible_scores) == set(bpp)
+    assert len(fs.hairpin_scores) == int((~np.isnan(rhp)).sum())
+    assert len(fs.twoloop_scores) == len(rtl)
+    for e in rtl[:: max(1, len(rtl) // 200)]:
+        key = (int(e["i"]), int(e["j"]), int(e["k"]), int(e["l"]))
+        assert np.float32(fs.twoloop_scores[key]) == e["score"]
+    from rna_algos_amd.mccaskill_algo import bpp_index
+    for (i, j), v in fs.accessible_scores.items():
+        assert np.float32(v) == rac[bpp_index(n, i, j)]

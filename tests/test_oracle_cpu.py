@@ -187,3 +187,50 @@ def test_thread_pool_batch_equals_sequential(params):
     for s, o, lz in zip(seqs, outs, logz):
         ref, ref_lz = O.bpp(params.ptr, s, 1, 0)
         assert np.array_equal(o, ref) and lz == ref_lz
+
+
+@pytest.mark.parametrize("contra,short", [(0, 0), (1, 0), (1, 1)])
+def test_fold_scores_key_sets(params, trnas, contra, short):
+    """FoldScores as the reference's inside pass fills it (src/mccaskill_algo.rs:302-304,
+    320, 333-338 / 407-409, 431, 457-462): key-set invariants and loop-shape limits."""
+    rng = np.random.default_rng(77)
+    seqs = [trnas[0][1], rng.integers(0, 4, 40).astype(np.uint8), np.array([1, 2], np.uint8)]
+    for seq in seqs:
+        n = len(seq)
+        hp, mb, ac, tl = O.fold_scores(params.ptr, seq, contra, short)
+        _, _, mats = O.bpp_dump(params.ptr, seq, contra, short)
+        close = mats[0]
+        hp_m, mb_m, ac_m = (unpack(np.where(np.isnan(x), -1e30, x), n) > -1e29 for x in (hp, mb, ac))
+        iu = np.triu_indices(n)
+        member = close > -np.inf
+        assert (mb_m[iu] == member[iu]).all() and (ac_m[iu] == member[iu]).all()
+        for i in range(n):
+            for j in range(i, n):
+                act = canon(seq[i], seq[j]) and ((contra and short) or j - i + 1 >= 5)
+                want_hp = act and (not contra or j - i - 1 <= 30)
+                assert hp_m[i, j] == want_hp, (i, j)
+        # multibranch_close values are the ones the outside pass read (dump slot 4)
+        mbv = unpack(np.where(np.isnan(mb), -1.0, mb), n)
+        assert (mbv[member] == mats[4][member]).all()
+        # twoloop keys: closing pair may close, enclosed pair has a sums_close entry,
+        # strictly nested, at most 30 unpaired bases; no duplicates
+        keys = set()
+        for e in tl:
+            i, j, k, l = int(e["i"]), int(e["j"]), int(e["k"]), int(e["l"])
+            assert i < k < l < j and (k - i - 1) + (j - l - 1) <= 30
+            assert canon(seq[i], seq[j]) and ((contra and short) or j - i + 1 >= 5)
+            assert member[k, l]
+            keys.add((i, j, k, l))
+        assert len(keys) == len(tl)
+        # completeness: every admissible (i,j,k,l) is there
+        want = 0
+        for i in range(n):
+            for j in range(i + 3, n):
+                if not (canon(seq[i], seq[j]) and ((contra and short) or j - i + 1 >= 5)):
+                    continue
+                for k in range(i + 1, min(j - 1, i + 32)):
+                    for l in range(j - 1, k, -1):
+                        if (k - i - 1) + (j - l - 1) > 30:
+                            break
+                        want += bool(member[k, l])
+        assert want == len(tl)
