@@ -52,6 +52,7 @@ struct rnamc_ctx {
   int64_t group_ws_bytes = 64ll << 30;
   int64_t block_threads = 256;
   int64_t profile = 0;
+  int64_t fuse_inside = 1;  // Turner: fold two diagonals per launch where launches are large
   int64_t debug_roles = 15;  // timing experiments only: bit0 folds, 1 pair block, 2 mb, 3 pair probs
   // bookkeeping of the last call
   rnamc_batch_stats stats{};
@@ -246,15 +247,57 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 0], st));
     launch_init(b, nseq, gmax, st);
     c->stats.launches_other++;
-    if (dmin_in > 0 && dmin_in < gmax) {  // closing-pair block of the first diagonal
-      launch_inside(b, contra, dmin_in - 1, gmax, active(dmin_in), block, false,
-                    (c->debug_roles & 2) != 0, st);
-      c->stats.launches_inside++;
-    }
-    for (uint32_t d = dmin_in; d < gmax; d++) {
-      launch_inside(b, contra, d, gmax, active(d), block, (c->debug_roles & 1) != 0,
-                    d + 1 < gmax && (c->debug_roles & 2) != 0, st);
-      c->stats.launches_inside++;
+    // Inside sweep.  Dependencies: the closing-pair block of diagonal D is a left fold whose
+    // early part (hairpin, 2-loops) needs sums_close of diagonals <= D-2 and whose last term
+    // needs the folds of diagonal D-2; the folds of diagonal D need the pair blocks of
+    // diagonals <= D (<= D+1 for the second cell of a two-diagonal launch).
+    //   one-diagonal launch d : folds(d) beside the whole pair block of d+1
+    //   two-diagonal launch d : folds(d, d+1) beside the early part of pair blocks d+2, d+3;
+    //                           their last term follows in a small launch of its own
+    // `pairs_done`: pair blocks complete up to here; `heads_done`: early part parked.
+    const bool do_sums = (c->debug_roles & 1) != 0, do_pair = (c->debug_roles & 2) != 0;
+    int64_t pairs_done = static_cast<int64_t>(dmin_in) - 1;  // nothing pairs below dmin_in
+    int64_t heads_done = pairs_done;
+    auto need_pairs = [&](int64_t upto) {  // complete the pair blocks of diagonals <= upto
+      upto = std::min<int64_t>(upto, static_cast<int64_t>(gmax) - 1);
+      while (pairs_done < upto) {
+        const uint32_t D = static_cast<uint32_t>(pairs_done + 1);
+        if (static_cast<int64_t>(D) <= heads_done) {
+          const uint32_t nd = static_cast<uint32_t>(std::min<int64_t>(heads_done, upto)) - D + 1;
+          if (do_pair) {
+            launch_pair_tail(b, D, nd, gmax, active(D), block, st);
+            c->stats.launches_inside++;
+          }
+          pairs_done = D + nd - 1;
+        } else {
+          if (D >= 1 && do_pair) {
+            launch_inside(b, contra, D - 1, gmax, active(D), block, false, true, st);
+            c->stats.launches_inside++;
+          }
+          pairs_done = D;
+          heads_done = std::max(heads_done, pairs_done);
+        }
+      }
+    };
+    for (uint32_t d = dmin_in; d < gmax;) {
+      const bool fuse = !contra && c->fuse_inside != 0 && d >= 2 && d + 1 < gmax &&
+                        !inside_is_split(d, gmax, active(d));
+      if (fuse) {
+        need_pairs(static_cast<int64_t>(d) + 1);
+        const bool head = heads_done < static_cast<int64_t>(d) + 2 && d + 2 < gmax;
+        launch_inside2(b, d, gmax, active(d), block, do_sums, head && do_pair, st);
+        c->stats.launches_inside++;
+        if (head) heads_done = std::min<int64_t>(static_cast<int64_t>(d) + 3, gmax - 1);
+        d += 2;
+      } else {
+        need_pairs(d);
+        // the whole pair block of d+1 rides along unless its early part is parked already
+        const bool pair_next = heads_done < static_cast<int64_t>(d) + 1 && d + 1 < gmax;
+        launch_inside(b, contra, d, gmax, active(d), block, do_sums, pair_next && do_pair, st);
+        c->stats.launches_inside++;
+        if (pair_next) pairs_done = heads_done = d + 1;
+        d += 1;
+      }
     }
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 1], st));
     // launch d carries the 2-loop half of diagonal d-1: start one diagonal early
@@ -419,6 +462,8 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     c->block_threads = value;
   } else if (k == "profile") {
     c->profile = value;
+  } else if (k == "fuse_inside") {
+    c->fuse_inside = value;
   } else if (k == "debug_roles") {
     c->debug_roles = value;
   } else {

@@ -367,7 +367,14 @@ __device__ __forceinline__ bool listed_cell(const Seq& q, uint32_t d, uint32_t t
 // ----------------------------------------------------------------------------
 // inside pass, closing-pair block of one cell of diagonal d
 // (src/mccaskill_algo.rs:297-343 Turner, 400-467 CONTRAfold)
-template <bool CONTRA>
+// The block is a left fold: hairpin, the <= 496 enclosed pairs, then the multibranch
+// term.  Everything but the last term needs only sums_close of spans <= d-2, so the
+// two-diagonal schedule evaluates that part early (PAIR_HEAD: the running sum is parked
+// in the sums_close slot) beside the folds of older diagonals, and adds the multibranch
+// term once sums_multibranch of diagonal d-2 exists (PAIR_TAIL).  PAIR_FULL does both.
+enum PairMode { PAIR_FULL = 0, PAIR_HEAD = 1, PAIR_TAIL = 2 };
+
+template <bool CONTRA, int MODE>
 __device__ __forceinline__ void inside_pair_cell(const DeviceBatch& b, const Seq& q, uint32_t d,
                                                  uint32_t i, bool valid, const LseTab* tab,
                                                  const ProbeTabs& L) {
@@ -378,22 +385,32 @@ __device__ __forceinline__ void inside_pair_cell(const DeviceBatch& b, const Seq
   if (!(b.allows_short_hairpins && CONTRA) && d + 1 < RNAMC_MIN_SPAN_HAIRPIN_CLOSE) act = false;
   if (__ballot(act) == 0ull) return;
   const auto model = ModelOf<CONTRA>::make(b);
+  const uint32_t o = tri_off(n, d) + i;
 
   float sum = kNegInf;
-  if (act && (!CONTRA || d - 1 <= RNAMC_MAX_LOOP_LEN)) sum = lse(sum, model.hairpin(s, n, i, j), tab);
-  // enclosed pairs (k,l) = (i+1+a, j-1-bb), a ascending, bb ascending (l descending),
-  // a+bb <= 30, k < j-1, l > k   <=>   a + bb <= d-3   (uniform over the diagonal)
-  if (d >= 3) {
-    const uint32_t lim = min(static_cast<uint32_t>(RNAMC_MAX_2LOOP_LEN), d - 3);
-    sum = probe_fold<CONTRA, false>(b, q, d, i, act, lim, sum, 0.f, tab, L);
+  if (MODE != PAIR_TAIL) {
+    if (act && (!CONTRA || d - 1 <= RNAMC_MAX_LOOP_LEN))
+      sum = lse(sum, model.hairpin(s, n, i, j), tab);
+    // enclosed pairs (k,l) = (i+1+a, j-1-bb), a ascending, bb ascending (l descending),
+    // a+bb <= 30, k < j-1, l > k   <=>   a + bb <= d-3   (uniform over the diagonal)
+    if (d >= 3) {
+      const uint32_t lim = min(static_cast<uint32_t>(RNAMC_MAX_2LOOP_LEN), d - 3);
+      sum = probe_fold<CONTRA, false>(b, q, d, i, act, lim, sum, 0.f, tab, L);
+    }
+    if (!act) return;
+    if (MODE == PAIR_HEAD) {
+      q.m[M_QB][o] = sum;
+      return;
+    }
+  } else {
+    if (!act) return;
+    sum = q.m[M_QB][o];
   }
-  if (!act) return;
   const float mbc = model.mbclose(s, n, i, j);
   const float qm = (d >= 2) ? q.m[M_QM][tri_off(n, d - 2) + i + 1] : kNegInf;
   sum = lse(sum, qm + mbc, tab);
   const float acc = model.accessible(s, n, i, j);
   if (sum > kNegInf) {
-    const uint32_t o = tri_off(n, d) + i;
     q.m[M_MBC][o] = mbc;
     q.m[M_QB][o] = sum;
     q.m[M_QA][o] = sum + acc;
@@ -514,6 +531,96 @@ __device__ __forceinline__ void inside_sums_cell(const DeviceBatch& b, const Seq
   s1 = lse(s1, s2, tab);
   q.m[M_Q1D][od] = s1;
   if (i >= 1) q.m[M_Q1C][col_off(i + d) + i - 1] = s1;  // column j, shifted one row up
+}
+
+// Two diagonals per lane (Turner): the folds of cells (i, i+d) and (i, i+d+1) walk the
+// same row operands sums_external(i,k-1) / sums_1ormore(i,k-1), so one lane folds both
+// cells off one stream of them: 4 loads per 6 fold steps instead of 6, and the second
+// column operand Zr(k, j+1) is the neighbouring lane's first-column operand of the step
+// before (same cache lines).  Needs the closing-pair blocks of diagonals d and d+1 done
+// (sums_multibranch of diagonals <= d-1) and every fold of diagonals <= d-1.
+// The one operand that a neighbouring lane produces in this very launch,
+// Zr(i+1, j+1) = Zr(i+1, j) (+) sums_accessible(i+1, j+1), is one fold step from values
+// that are already final, and is recomputed here.  Same operations per cell, in the
+// same order, as inside_sums_cell.
+__device__ __forceinline__ void inside_sums_pair2(const DeviceBatch& b, const Seq& q, uint32_t d,
+                                                  uint32_t i, const LseTab* tab) {
+  const uint32_t n = q.n;
+  const uint32_t odA = tri_off(n, d) + i, odB = tri_off(n, d + 1) + i;
+  const bool hasB = i + d + 1 < n;
+  const float* __restrict__ zre = q.m[M_ZRE];
+  const float* __restrict__ z = q.m[M_Z];
+  const float* __restrict__ q1 = q.m[M_Q1D];
+  const float* __restrict__ qa = q.m[M_QA];
+  const float c = b.params->turner.coeff_num_branches;
+
+  const float zrA = lse(zre[tri_off(n, d - 1) + i], qa[odA], tab);
+  const float zrB = lse(zrA, qa[odB], tab);  // pad makes the read safe when !hasB
+  // Zr(i+1, j+1): diagonal d, offset i+1
+  const float zrN = lse(zre[tri_off(n, d - 1) + i + 1], qa[odA + 1], tab);
+  q.m[M_ZRE][odA] = zrA;
+  if (hasB) q.m[M_ZRE][odB] = zrB;
+
+  float extA = lse(0.f, zrA + 0.f, tab), s1A = zrA + c, s2A = kNegInf;
+  float extB = lse(0.f, zrB + 0.f, tab), s1B = zrB + c, s2B = kNegInf;
+  auto step = [&](float ra, float rb, float zz, float qq) {
+    extA = lse(extA, ra + zz, tab);
+    extB = lse(extB, rb + zz, tab);
+    const float xa = ra + c, xb = rb + c;
+    s1A = lse(s1A, xa, tab);
+    s1B = lse(s1B, xb, tab);
+    s2A = lse(s2A, qq + xa, tab);
+    s2B = lse(s2B, qq + xb, tab);
+  };
+  const uint32_t i4 = i * 4u;
+  struct SBuf {
+    float ra[kU], rb[kU], zz[kU], qq[kU];
+  };
+  // steps 1 .. d-1 of both cells: k = i + t
+  uint32_t t = pingpong<SBuf, kU, true>(
+      1u, (d - 1) / kU,
+      [&](SBuf& B, uint32_t t0) {
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+          const uint32_t oa = tri_off(n, d - t0 - u) + t0 + u;
+          const uint32_t ob = tri_off(n, d + 1 - t0 - u) + t0 + u;
+          const uint32_t o = tri_off(n, t0 + u - 1);
+          B.ra[u] = ldu(zre + oa, i4);
+          B.rb[u] = ldu(zre + ob, i4);
+          B.zz[u] = ldu(z + o, i4);
+          B.qq[u] = ldu(q1 + o, i4);
+        }
+      },
+      [&](const SBuf& B, uint32_t t0) {
+#pragma unroll
+        for (int u = 0; u < kU; u++)
+          step(B.ra[u], (t0 + u == 1u) ? zrN : B.rb[u], B.zz[u], B.qq[u]);
+      });
+  for (; t < d; t++) {
+    const uint32_t o = tri_off(n, t - 1) + i;
+    const float rb = (t == 1u) ? zrN : zre[tri_off(n, d + 1 - t) + t + i];
+    step(zre[tri_off(n, d - t) + t + i], rb, z[o], q1[o]);
+  }
+  q.m[M_Z][odA] = extA;
+  q.m[M_QM][odA] = s2A;
+  s1A = lse(s1A, s2A, tab);
+  q.m[M_Q1D][odA] = s1A;
+  if (i >= 1) q.m[M_Q1C][col_off(i + d) + i - 1] = s1A;
+  if (!hasB) return;
+  {  // step t = d of the second cell: k = j
+    const uint32_t o = tri_off(n, d - 1) + i;
+    const float rb = (d == 1u) ? zrN : zre[tri_off(n, 1) + d + i];
+    const float zz = z[o], qq = q1[o];
+    extB = lse(extB, rb + zz, tab);
+    const float xb = rb + c;
+    s1B = lse(s1B, xb, tab);
+    s2B = lse(s2B, qq + xb, tab);
+  }
+  q.m[M_Z][odB] = extB;
+  q.m[M_QM][odB] = s2B;
+  s1B = lse(s1B, s2B, tab);
+  q.m[M_Q1D][odB] = s1B;
+  if (i >= 1) q.m[M_Q1C][col_off(i + d + 1) + i - 1] = s1B;
 }
 
 // Latency form of the folds for launches too small to fill the chip (a single long
@@ -670,8 +777,62 @@ __global__ void __launch_bounds__(256) k_inside(DeviceBatch b, uint32_t d, uint3
     if (t - (threadIdx.x & 63u) >= cnt) return;  // wave past the list
     uint32_t i;
     const bool valid = listed_cell(q, dp, t, cnt, i);
-    inside_pair_cell<CONTRA>(b, q, dp, i, valid, tab, L);
+    inside_pair_cell<CONTRA, PAIR_FULL>(b, q, dp, i, valid, tab, L);
   }
+}
+
+// Two-diagonal launch (Turner): blocks [0, blocks_sums) fold diagonals d and d+1
+// (inside_sums_pair2); then blocks_head blocks each for the early part of the closing-pair
+// blocks of diagonals d+2 and d+3, which needs sums_close of spans <= d+1 only.
+__global__ void __launch_bounds__(256) k_inside2(DeviceBatch b, uint32_t d, uint32_t blocks_sums,
+                                                 uint32_t blocks_head, uint32_t nseq, int do_sums,
+                                                 int do_head) {
+  __shared__ LseTab tabs;
+  __shared__ ProbeTabs L;
+  load_lse_table(&tabs);
+  const uint32_t bxr = blockIdx.x / nseq;
+  const uint32_t which = blockIdx.x - bxr * nseq;
+  const Seq q = load_seq(b, which);
+  const uint32_t n = q.n;
+  if (bxr < blocks_sums) {
+    const uint32_t i = bxr * blockDim.x + threadIdx.x;
+    if (!do_sums || d >= n || i >= n - d) return;
+    inside_sums_pair2(b, q, d, i, &tabs);
+  } else {
+    const uint32_t hb = bxr - blocks_sums;
+    const uint32_t dp = d + 2 + hb / blocks_head;
+    const uint32_t blk = hb % blocks_head;
+    if (!do_head || dp >= n) return;
+    const uint32_t cnt = q.ccnt[dp];
+    if (blk * blockDim.x >= cnt) return;
+    load_probe_tabs<false, false>(L, b.params);
+    const uint32_t t = blk * blockDim.x + threadIdx.x;
+    if (t - (threadIdx.x & 63u) >= cnt) return;
+    uint32_t i;
+    const bool valid = listed_cell(q, dp, t, cnt, i);
+    inside_pair_cell<false, PAIR_HEAD>(b, q, dp, i, valid, &tabs, L);
+  }
+}
+
+// multibranch term of the closing-pair blocks of diagonals d0 .. d0+nd-1 whose early part
+// is parked (Turner two-diagonal schedule)
+__global__ void __launch_bounds__(256) k_pair_tail(DeviceBatch b, uint32_t d0, uint32_t blocks_d,
+                                                   uint32_t nseq) {
+  __shared__ LseTab tabs;
+  __shared__ ProbeTabs L;  // unused by PAIR_TAIL, keeps one signature for the cell function
+  load_lse_table(&tabs);
+  const uint32_t bxr = blockIdx.x / nseq;
+  const uint32_t which = blockIdx.x - bxr * nseq;
+  const Seq q = load_seq(b, which);
+  const uint32_t dp = d0 + bxr / blocks_d;
+  const uint32_t blk = bxr % blocks_d;
+  if (dp >= q.n) return;
+  const uint32_t cnt = q.ccnt[dp];
+  const uint32_t t = blk * blockDim.x + threadIdx.x;
+  if (t - (threadIdx.x & 63u) >= cnt) return;
+  uint32_t i;
+  const bool valid = listed_cell(q, dp, t, cnt, i);
+  inside_pair_cell<false, PAIR_TAIL>(b, q, dp, i, valid, &tabs, L);
 }
 
 // ----------------------------------------------------------------------------
@@ -982,7 +1143,7 @@ void launch_inside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n
   const uint32_t cells_p = (do_pair && d + 1 < max_n) ? max_n - d - 1 : 0;
   // launches that cannot give every SIMD a wave are latency-bound: spread the three
   // chains of a cell over three lanes (21 cells per wave)
-  const bool split = static_cast<uint64_t>(cells_s) * nseq < 64ull * 1024ull;
+  const bool split = do_sums && inside_is_split(d, max_n, nseq);
   const uint32_t cells_per_block = split ? (block / 64) * kSplitCells : block;
   const uint32_t bs = (cells_s + cells_per_block - 1) / cells_per_block;
   const uint32_t bp = (cells_p + block - 1) / block;
@@ -1002,6 +1163,33 @@ void launch_inside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n
       hipLaunchKernelGGL((k_inside<false, false>), g, dim3(block), 0, st, b, d, bs, nseq, ds, dp);
     }
   }
+}
+
+// folds of diagonals d and d+1 (Turner, d >= 2; both closing-pair blocks done) and, if
+// do_head, the early part of the closing-pair blocks of diagonals d+2 and d+3
+void launch_inside2(const DeviceBatch& b, uint32_t d, uint32_t max_n, uint32_t nseq,
+                    uint32_t block, bool do_sums, bool do_head, hipStream_t st) {
+  if (d >= max_n || nseq == 0) return;
+  const uint32_t bs = do_sums ? (max_n - d + block - 1) / block : 0;
+  const uint32_t cells_h = (do_head && d + 2 < max_n) ? max_n - d - 2 : 0;
+  const uint32_t bh = std::max(1u, (cells_h + block - 1) / block);
+  const uint32_t nh = cells_h ? 2u : 0u;
+  if (bs + nh == 0) return;
+  hipLaunchKernelGGL(k_inside2, dim3((bs + nh * bh) * nseq, 1, 1), dim3(block), 0, st, b, d, bs,
+                     bh, nseq, do_sums ? 1 : 0, do_head ? 1 : 0);
+}
+
+// multibranch term of the parked closing-pair blocks of diagonals d0 .. d0+nd-1
+void launch_pair_tail(const DeviceBatch& b, uint32_t d0, uint32_t nd, uint32_t max_n,
+                      uint32_t nseq, uint32_t block, hipStream_t st) {
+  if (d0 >= max_n || nseq == 0 || nd == 0) return;
+  const uint32_t bd = (max_n - d0 + block - 1) / block;
+  hipLaunchKernelGGL(k_pair_tail, dim3(nd * bd * nseq, 1, 1), dim3(block), 0, st, b, d0, bd, nseq);
+}
+
+bool inside_is_split(uint32_t d, uint32_t max_n, uint32_t nseq) {
+  const uint32_t cells_s = d < max_n ? max_n - d : 0;
+  return static_cast<uint64_t>(cells_s) * nseq < 64ull * 1024ull;
 }
 
 // launch of diagonal d: probs_multibranch (do_mb) and multibranch half of the pair

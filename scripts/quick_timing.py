@@ -63,6 +63,8 @@ def main():
         ctx.set("debug_roles", int(os.environ["ROLES"]))
     if os.environ.get("WSGB"):
         ctx.set("group_ws_bytes", int(os.environ["WSGB"]) << 30)
+    if os.environ.get("FUSE"):
+        ctx.set("fuse_inside", int(os.environ["FUSE"]))
     if os.environ.get("BLOCK"):
         ctx.set("block_threads", int(os.environ["BLOCK"]))
     what = sys.argv[1:] or ["n1024", "n4096", "batch256"]

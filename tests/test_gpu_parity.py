@@ -406,3 +406,36 @@ def test_mccaskill_algo_returns_fold_scores(params, trnas):
     from rna_algos_amd.mccaskill_algo import bpp_index
     for (i, j), v in fs.accessible_scores.items():
         assert np.float32(v) == rac[bpp_index(n, i, j)]
+
+
+def test_two_diagonal_schedule_bit_exact(ctx, params):
+    """Large lock-step groups run the Turner inside sweep two diagonals per launch (folds of
+    d and d+1 off one operand stream, pair blocks split into an early and a last part).
+    Same bits as the oracle on a group big enough to take that schedule, and the same bits
+    as the one-diagonal schedule on longer sequences."""
+    rng = np.random.default_rng(31)
+    lens = rng.integers(180, 331, 420)
+    seqs = [rng.integers(0, 4, int(n)).astype(np.uint8) for n in lens]
+    mats, logz = ctx.bpp_batch(seqs, False, False)
+    ref, ref_logz = O.bpp_batch(params.ptr, seqs, False, False, n_threads=16)
+    for s, m, r in zip(seqs, mats, ref):
+        assert_same(m.packed, r, f"n={len(s)}")
+    assert np.array_equal(np.asarray(logz).view(np.uint32), np.asarray(ref_logz).view(np.uint32))
+    # longer folds: both schedules against each other (ragged group, odd and even lengths)
+    lens = rng.integers(500, 701, 260)
+    seqs = [rng.integers(0, 4, int(n)).astype(np.uint8) for n in lens]
+    try:
+        ctx.set("fuse_inside", 0)
+        one, logz1 = ctx.bpp_batch(seqs, False, False)
+        ctx.set("fuse_inside", 1)
+        two, logz2 = ctx.bpp_batch(seqs, False, False)
+    finally:
+        ctx.set("fuse_inside", 1)
+    for a, b in zip(one, two):
+        assert np.array_equal(np.asarray(a.packed).view(np.uint32), np.asarray(b.packed).view(np.uint32))
+    assert np.array_equal(np.asarray(logz1).view(np.uint32), np.asarray(logz2).view(np.uint32))
+    # and one member of the second batch against the oracle
+    k = int(np.argmax(lens))
+    r, rz = O.bpp(params.ptr, seqs[k], False, False)
+    assert_same(two[k].packed, r, "longest member")
+    assert np.float32(logz2[k]).view(np.uint32) == np.float32(rz).view(np.uint32)
