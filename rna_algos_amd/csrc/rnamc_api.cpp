@@ -265,7 +265,7 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
         if (static_cast<int64_t>(D) <= heads_done) {
           const uint32_t nd = static_cast<uint32_t>(std::min<int64_t>(heads_done, upto)) - D + 1;
           if (do_pair) {
-            launch_pair_tail(b, D, nd, gmax, active(D), block, st);
+            launch_pair_tail(b, contra, D, nd, gmax, active(D), block, st);
             c->stats.launches_inside++;
           }
           pairs_done = D + nd - 1;
@@ -280,12 +280,16 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
       }
     };
     for (uint32_t d = dmin_in; d < gmax;) {
-      const bool fuse = !contra && c->fuse_inside != 0 && d >= 2 && d + 1 < gmax &&
+      const bool fuse = c->fuse_inside != 0 && d >= 2 && d + 1 < gmax &&
                         !inside_is_split(d, gmax, active(d));
       if (fuse) {
         need_pairs(static_cast<int64_t>(d) + 1);
         const bool head = heads_done < static_cast<int64_t>(d) + 2 && d + 2 < gmax;
-        launch_inside2(b, d, gmax, active(d), block, do_sums, head && do_pair, st);
+        if (contra && do_sums) {
+          launch_inside_zr2(b, d, gmax, active(d), block, st);
+          c->stats.launches_inside++;
+        }
+        launch_inside2(b, contra, d, gmax, active(d), block, do_sums, head && do_pair, st);
         c->stats.launches_inside++;
         if (head) heads_done = std::min<int64_t>(static_cast<int64_t>(d) + 3, gmax - 1);
         d += 2;

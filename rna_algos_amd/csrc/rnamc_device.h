@@ -28,12 +28,16 @@ void launch_init(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, hipStream_
 // folds of diagonal d (do_sums) and closing-pair block of diagonal d+1 (do_pair)
 void launch_inside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
                    uint32_t block, bool do_sums, bool do_pair, hipStream_t st);
-// Turner two-diagonal schedule: folds of diagonals d and d+1 (pair blocks of d and d+1
-// done) beside the early part of the pair blocks of d+2 and d+3 (do_head)
-void launch_inside2(const DeviceBatch& b, uint32_t d, uint32_t max_n, uint32_t nseq,
+// Two-diagonal schedule: folds of diagonals d and d+1 (pair blocks of d and d+1 done; for
+// CONTRAfold also launch_inside_zr2 of the same d) beside the early part of the pair
+// blocks of d+2 and d+3 (do_head)
+void launch_inside2(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
                     uint32_t block, bool do_sums, bool do_head, hipStream_t st);
+// CONTRAfold: sums_rightmost_basepairs_{external,multibranch} of diagonals d and d+1
+void launch_inside_zr2(const DeviceBatch& b, uint32_t d, uint32_t max_n, uint32_t nseq,
+                       uint32_t block, hipStream_t st);
 // last (multibranch) term of the parked pair blocks of diagonals d0 .. d0+nd-1
-void launch_pair_tail(const DeviceBatch& b, uint32_t d0, uint32_t nd, uint32_t max_n,
+void launch_pair_tail(const DeviceBatch& b, bool contra, uint32_t d0, uint32_t nd, uint32_t max_n,
                       uint32_t nseq, uint32_t block, hipStream_t st);
 // true when the folds of diagonal d run in the latency form (launch too small to fill the chip)
 bool inside_is_split(uint32_t d, uint32_t max_n, uint32_t nseq);

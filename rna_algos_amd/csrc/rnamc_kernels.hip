@@ -533,48 +533,129 @@ __device__ __forceinline__ void inside_sums_cell(const DeviceBatch& b, const Seq
   if (i >= 1) q.m[M_Q1C][col_off(i + d) + i - 1] = s1;  // column j, shifted one row up
 }
 
-// Two diagonals per lane (Turner): the folds of cells (i, i+d) and (i, i+d+1) walk the
-// same row operands sums_external(i,k-1) / sums_1ormore(i,k-1), so one lane folds both
-// cells off one stream of them: 4 loads per 6 fold steps instead of 6, and the second
-// column operand Zr(k, j+1) is the neighbouring lane's first-column operand of the step
-// before (same cache lines).  Needs the closing-pair blocks of diagonals d and d+1 done
-// (sums_multibranch of diagonals <= d-1) and every fold of diagonals <= d-1.
-// The one operand that a neighbouring lane produces in this very launch,
-// Zr(i+1, j+1) = Zr(i+1, j) (+) sums_accessible(i+1, j+1), is one fold step from values
-// that are already final, and is recomputed here.  Same operations per cell, in the
-// same order, as inside_sums_cell.
+// Two diagonals per lane: the folds of cells (i, i+d) and (i, i+d+1) walk the same row
+// operands sums_external(i,k-1) / sums_1ormore(i,k-1), so one lane folds both cells off
+// one stream of them (4 loads per 6 fold steps instead of 6; the second cell's column
+// operand Zr(k, j+1) is the neighbouring lane's first-column operand of the step before:
+// same cache lines).  Needs the closing-pair blocks of diagonals d and d+1 done
+// (sums_multibranch of diagonals <= d-1) and every fold of diagonals <= d-1.  Same
+// operations per cell, in the same order, as inside_sums_cell.
+//
+// Turner: the rightmost-pair sums are one fold step from final values; Zr(i+1, j+1), which
+// a neighbouring lane produces in this very launch, is recomputed here.
+// CONTRAfold: they are folds of their own (inside_zr_pair2, the launch before this one).
+
+// CONTRAfold: sums_rightmost_basepairs_{external,multibranch} of cells (i, i+d) and
+// (i, i+d+1) off one stream of sums_accessible(i, k) (src/mccaskill_algo.rs:468-486)
+__device__ __forceinline__ void inside_zr_pair2(const DeviceBatch& b, const Seq& q, uint32_t d,
+                                                uint32_t i, const LseTab* tab) {
+  const uint32_t n = q.n;
+  const bool hasB = i + d + 1 < n;
+  const rnamc_fold_score_sets& f = b.params->contra;
+  const float ebp = f.external_score_basepair, eun = f.external_score_unpair;
+  const float mbp = f.multibranch_score_basepair, mun = f.multibranch_score_unpair;
+  const float* __restrict__ qa = q.m[M_QA];
+  float eA = kNegInf, mA = kNegInf, eB = kNegInf, mB = kNegInf;
+  // k = i + t; j - k = d - t for the first cell, d + 1 - t for the second
+  auto step = [&](float x, uint32_t t) {
+    const float ca = static_cast<float>(d - t), cb = static_cast<float>(d + 1 - t);
+    eA = lse(eA, x + ebp + eun * ca, tab);
+    eB = lse(eB, x + ebp + eun * cb, tab);
+    mA = lse(mA, x + mbp + mun * ca, tab);
+    mB = lse(mB, x + mbp + mun * cb, tab);
+  };
+  struct ABuf {
+    float xs[kU];
+  };
+  uint32_t t = pingpong<ABuf, kU, true>(
+      1u, d / kU,
+      [&](ABuf& B, uint32_t t0) {
+#pragma unroll
+        for (int u = 0; u < kU; u++) B.xs[u] = ldu(qa + tri_off(n, t0 + u), i * 4u);
+      },
+      [&](const ABuf& B, uint32_t t0) {
+#pragma unroll
+        for (int u = 0; u < kU; u++) step(B.xs[u], t0 + u);
+      });
+  for (; t <= d; t++) step(qa[tri_off(n, t) + i], t);
+  const uint32_t odA = tri_off(n, d) + i, odB = tri_off(n, d + 1) + i;
+  q.m[M_ZRE][odA] = eA;
+  q.m[M_ZRM][odA] = mA;
+  if (!hasB) return;
+  {  // k = j + 1 of the second cell
+    const float x = qa[odB];
+    eB = lse(eB, x + ebp + eun * 0.f, tab);
+    mB = lse(mB, x + mbp + mun * 0.f, tab);
+  }
+  q.m[M_ZRE][odB] = eB;
+  q.m[M_ZRM][odB] = mB;
+}
+
+template <bool CONTRA>
 __device__ __forceinline__ void inside_sums_pair2(const DeviceBatch& b, const Seq& q, uint32_t d,
                                                   uint32_t i, const LseTab* tab) {
   const uint32_t n = q.n;
   const uint32_t odA = tri_off(n, d) + i, odB = tri_off(n, d + 1) + i;
   const bool hasB = i + d + 1 < n;
   const float* __restrict__ zre = q.m[M_ZRE];
+  const float* __restrict__ zrm = q.m[CONTRA ? M_ZRM : M_ZRE];
   const float* __restrict__ z = q.m[M_Z];
   const float* __restrict__ q1 = q.m[M_Q1D];
   const float* __restrict__ qa = q.m[M_QA];
-  const float c = b.params->turner.coeff_num_branches;
+  const float c = CONTRA ? 0.f : b.params->turner.coeff_num_branches;
+  const float mun = CONTRA ? b.params->contra.multibranch_score_unpair : 0.f;
 
-  const float zrA = lse(zre[tri_off(n, d - 1) + i], qa[odA], tab);
-  const float zrB = lse(zrA, qa[odB], tab);  // pad makes the read safe when !hasB
-  // Zr(i+1, j+1): diagonal d, offset i+1
-  const float zrN = lse(zre[tri_off(n, d - 1) + i + 1], qa[odA + 1], tab);
-  q.m[M_ZRE][odA] = zrA;
-  if (hasB) q.m[M_ZRE][odB] = zrB;
+  float zeA, zmA, zeB, zmB, zrN = 0.f;
+  if (!CONTRA) {
+    zeA = lse(zre[tri_off(n, d - 1) + i], qa[odA], tab);
+    zeB = lse(zeA, qa[odB], tab);  // pad makes the read safe when !hasB
+    // Zr(i+1, j+1): diagonal d, offset i+1
+    zrN = lse(zre[tri_off(n, d - 1) + i + 1], qa[odA + 1], tab);
+    zmA = zeA;
+    zmB = zeB;
+    q.m[M_ZRE][odA] = zeA;
+    if (hasB) q.m[M_ZRE][odB] = zeB;
+  } else {
+    zeA = zre[odA];
+    zmA = zrm[odA];
+    zeB = zre[odB];
+    zmB = zrm[odB];
+  }
 
-  float extA = lse(0.f, zrA + 0.f, tab), s1A = zrA + c, s2A = kNegInf;
-  float extB = lse(0.f, zrB + 0.f, tab), s1B = zrB + c, s2B = kNegInf;
-  auto step = [&](float ra, float rb, float zz, float qq) {
-    extA = lse(extA, ra + zz, tab);
-    extB = lse(extB, rb + zz, tab);
-    const float xa = ra + c, xb = rb + c;
-    s1A = lse(s1A, xa, tab);
-    s1B = lse(s1B, xb, tab);
-    s2A = lse(s2A, qq + xa, tab);
-    s2B = lse(s2B, qq + xb, tab);
+  float extA, extB, s1A, s1B, s2A = kNegInf, s2B = kNegInf;
+  if (!CONTRA) {
+    extA = lse(0.f, zeA + 0.f, tab);  // k = i: Z[i][i-1] is the lower-triangle 0
+    extB = lse(0.f, zeB + 0.f, tab);
+    s1A = zeA + c;
+    s1B = zeB + c;
+  } else {
+    const float eun = b.params->contra.external_score_unpair;
+    extA = lse(eun * static_cast<float>(d + 1), zeA + 0.f, tab);
+    extB = lse(eun * static_cast<float>(d + 2), zeB + 0.f, tab);
+    s1A = zmA;
+    s1B = zmB;
+  }
+  // ea/ma: Zr_ext / Zr_mb of column j, eb/mb of column j+1 (Turner: ma = ea, mb = eb)
+  auto step = [&](float ea, float ma, float eb, float mb, float zz, float qq, uint32_t t) {
+    extA = lse(extA, ea + zz, tab);
+    extB = lse(extB, eb + zz, tab);
+    if (!CONTRA) {
+      const float xa = ea + c, xb = eb + c;
+      s1A = lse(s1A, xa, tab);
+      s1B = lse(s1B, xb, tab);
+      s2A = lse(s2A, qq + xa, tab);
+      s2B = lse(s2B, qq + xb, tab);
+    } else {
+      const float tt = mun * static_cast<float>(t);
+      s1A = lse(s1A, ma + tt, tab);
+      s1B = lse(s1B, mb + tt, tab);
+      s2A = lse(s2A, qq + ma, tab);
+      s2B = lse(s2B, qq + mb, tab);
+    }
   };
   const uint32_t i4 = i * 4u;
   struct SBuf {
-    float ra[kU], rb[kU], zz[kU], qq[kU];
+    float ea[kU], ma[kU], eb[kU], mb[kU], zz[kU], qq[kU];
   };
   // steps 1 .. d-1 of both cells: k = i + t
   uint32_t t = pingpong<SBuf, kU, true>(
@@ -585,21 +666,26 @@ __device__ __forceinline__ void inside_sums_pair2(const DeviceBatch& b, const Se
           const uint32_t oa = tri_off(n, d - t0 - u) + t0 + u;
           const uint32_t ob = tri_off(n, d + 1 - t0 - u) + t0 + u;
           const uint32_t o = tri_off(n, t0 + u - 1);
-          B.ra[u] = ldu(zre + oa, i4);
-          B.rb[u] = ldu(zre + ob, i4);
+          B.ea[u] = ldu(zre + oa, i4);
+          B.eb[u] = ldu(zre + ob, i4);
+          B.ma[u] = CONTRA ? ldu(zrm + oa, i4) : 0.f;
+          B.mb[u] = CONTRA ? ldu(zrm + ob, i4) : 0.f;
           B.zz[u] = ldu(z + o, i4);
           B.qq[u] = ldu(q1 + o, i4);
         }
       },
       [&](const SBuf& B, uint32_t t0) {
 #pragma unroll
-        for (int u = 0; u < kU; u++)
-          step(B.ra[u], (t0 + u == 1u) ? zrN : B.rb[u], B.zz[u], B.qq[u]);
+        for (int u = 0; u < kU; u++) {
+          const float eb = (!CONTRA && t0 + u == 1u) ? zrN : B.eb[u];
+          step(B.ea[u], B.ma[u], eb, B.mb[u], B.zz[u], B.qq[u], t0 + u);
+        }
       });
   for (; t < d; t++) {
+    const uint32_t oa = tri_off(n, d - t) + t + i, ob = tri_off(n, d + 1 - t) + t + i;
     const uint32_t o = tri_off(n, t - 1) + i;
-    const float rb = (t == 1u) ? zrN : zre[tri_off(n, d + 1 - t) + t + i];
-    step(zre[tri_off(n, d - t) + t + i], rb, z[o], q1[o]);
+    const float eb = (!CONTRA && t == 1u) ? zrN : zre[ob];
+    step(zre[oa], CONTRA ? zrm[oa] : 0.f, eb, CONTRA ? zrm[ob] : 0.f, z[o], q1[o], t);
   }
   q.m[M_Z][odA] = extA;
   q.m[M_QM][odA] = s2A;
@@ -608,13 +694,19 @@ __device__ __forceinline__ void inside_sums_pair2(const DeviceBatch& b, const Se
   if (i >= 1) q.m[M_Q1C][col_off(i + d) + i - 1] = s1A;
   if (!hasB) return;
   {  // step t = d of the second cell: k = j
-    const uint32_t o = tri_off(n, d - 1) + i;
-    const float rb = (d == 1u) ? zrN : zre[tri_off(n, 1) + d + i];
+    const uint32_t ob = tri_off(n, 1) + d + i, o = tri_off(n, d - 1) + i;
+    const float eb = (!CONTRA && d == 1u) ? zrN : zre[ob];
+    const float mb = CONTRA ? zrm[ob] : 0.f;
     const float zz = z[o], qq = q1[o];
-    extB = lse(extB, rb + zz, tab);
-    const float xb = rb + c;
-    s1B = lse(s1B, xb, tab);
-    s2B = lse(s2B, qq + xb, tab);
+    extB = lse(extB, eb + zz, tab);
+    if (!CONTRA) {
+      const float xb = eb + c;
+      s1B = lse(s1B, xb, tab);
+      s2B = lse(s2B, qq + xb, tab);
+    } else {
+      s1B = lse(s1B, mb + mun * static_cast<float>(d), tab);
+      s2B = lse(s2B, qq + mb, tab);
+    }
   }
   q.m[M_Z][odB] = extB;
   q.m[M_QM][odB] = s2B;
@@ -781,9 +873,11 @@ __global__ void __launch_bounds__(256) k_inside(DeviceBatch b, uint32_t d, uint3
   }
 }
 
-// Two-diagonal launch (Turner): blocks [0, blocks_sums) fold diagonals d and d+1
-// (inside_sums_pair2); then blocks_head blocks each for the early part of the closing-pair
-// blocks of diagonals d+2 and d+3, which needs sums_close of spans <= d+1 only.
+// Two-diagonal launch: blocks [0, blocks_sums) fold diagonals d and d+1
+// (inside_sums_pair2, or with ZR_ONLY the CONTRAfold rightmost-pair sums that precede
+// them); then blocks_head blocks each for the early part of the closing-pair blocks of
+// diagonals d+2 and d+3, which needs sums_close of spans <= d+1 only.
+template <bool CONTRA, bool ZR_ONLY>
 __global__ void __launch_bounds__(256) k_inside2(DeviceBatch b, uint32_t d, uint32_t blocks_sums,
                                                  uint32_t blocks_head, uint32_t nseq, int do_sums,
                                                  int do_head) {
@@ -797,7 +891,11 @@ __global__ void __launch_bounds__(256) k_inside2(DeviceBatch b, uint32_t d, uint
   if (bxr < blocks_sums) {
     const uint32_t i = bxr * blockDim.x + threadIdx.x;
     if (!do_sums || d >= n || i >= n - d) return;
-    inside_sums_pair2(b, q, d, i, &tabs);
+    if (ZR_ONLY) {
+      inside_zr_pair2(b, q, d, i, &tabs);
+    } else {
+      inside_sums_pair2<CONTRA>(b, q, d, i, &tabs);
+    }
   } else {
     const uint32_t hb = bxr - blocks_sums;
     const uint32_t dp = d + 2 + hb / blocks_head;
@@ -805,17 +903,18 @@ __global__ void __launch_bounds__(256) k_inside2(DeviceBatch b, uint32_t d, uint
     if (!do_head || dp >= n) return;
     const uint32_t cnt = q.ccnt[dp];
     if (blk * blockDim.x >= cnt) return;
-    load_probe_tabs<false, false>(L, b.params);
+    load_probe_tabs<CONTRA, false>(L, b.params);
     const uint32_t t = blk * blockDim.x + threadIdx.x;
     if (t - (threadIdx.x & 63u) >= cnt) return;
     uint32_t i;
     const bool valid = listed_cell(q, dp, t, cnt, i);
-    inside_pair_cell<false, PAIR_HEAD>(b, q, dp, i, valid, &tabs, L);
+    inside_pair_cell<CONTRA, PAIR_HEAD>(b, q, dp, i, valid, &tabs, L);
   }
 }
 
 // multibranch term of the closing-pair blocks of diagonals d0 .. d0+nd-1 whose early part
-// is parked (Turner two-diagonal schedule)
+// is parked (two-diagonal schedule)
+template <bool CONTRA>
 __global__ void __launch_bounds__(256) k_pair_tail(DeviceBatch b, uint32_t d0, uint32_t blocks_d,
                                                    uint32_t nseq) {
   __shared__ LseTab tabs;
@@ -832,7 +931,7 @@ __global__ void __launch_bounds__(256) k_pair_tail(DeviceBatch b, uint32_t d0, u
   if (t - (threadIdx.x & 63u) >= cnt) return;
   uint32_t i;
   const bool valid = listed_cell(q, dp, t, cnt, i);
-  inside_pair_cell<false, PAIR_TAIL>(b, q, dp, i, valid, &tabs, L);
+  inside_pair_cell<CONTRA, PAIR_TAIL>(b, q, dp, i, valid, &tabs, L);
 }
 
 // ----------------------------------------------------------------------------
@@ -1165,9 +1264,9 @@ void launch_inside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n
   }
 }
 
-// folds of diagonals d and d+1 (Turner, d >= 2; both closing-pair blocks done) and, if
-// do_head, the early part of the closing-pair blocks of diagonals d+2 and d+3
-void launch_inside2(const DeviceBatch& b, uint32_t d, uint32_t max_n, uint32_t nseq,
+// folds of diagonals d and d+1 (d >= 2; both closing-pair blocks done) and, if do_head, the
+// early part of the closing-pair blocks of diagonals d+2 and d+3
+void launch_inside2(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
                     uint32_t block, bool do_sums, bool do_head, hipStream_t st) {
   if (d >= max_n || nseq == 0) return;
   const uint32_t bs = do_sums ? (max_n - d + block - 1) / block : 0;
@@ -1175,16 +1274,35 @@ void launch_inside2(const DeviceBatch& b, uint32_t d, uint32_t max_n, uint32_t n
   const uint32_t bh = std::max(1u, (cells_h + block - 1) / block);
   const uint32_t nh = cells_h ? 2u : 0u;
   if (bs + nh == 0) return;
-  hipLaunchKernelGGL(k_inside2, dim3((bs + nh * bh) * nseq, 1, 1), dim3(block), 0, st, b, d, bs,
-                     bh, nseq, do_sums ? 1 : 0, do_head ? 1 : 0);
+  const dim3 g((bs + nh * bh) * nseq, 1, 1);
+  const int ds = do_sums ? 1 : 0, dh = do_head ? 1 : 0;
+  if (contra) {
+    hipLaunchKernelGGL((k_inside2<true, false>), g, dim3(block), 0, st, b, d, bs, bh, nseq, ds, dh);
+  } else {
+    hipLaunchKernelGGL((k_inside2<false, false>), g, dim3(block), 0, st, b, d, bs, bh, nseq, ds, dh);
+  }
+}
+
+// CONTRAfold: the rightmost-pair sums of diagonals d and d+1 (precede launch_inside2)
+void launch_inside_zr2(const DeviceBatch& b, uint32_t d, uint32_t max_n, uint32_t nseq,
+                       uint32_t block, hipStream_t st) {
+  if (d >= max_n || nseq == 0) return;
+  const uint32_t bs = (max_n - d + block - 1) / block;
+  hipLaunchKernelGGL((k_inside2<true, true>), dim3(bs * nseq, 1, 1), dim3(block), 0, st, b, d, bs,
+                     1u, nseq, 1, 0);
 }
 
 // multibranch term of the parked closing-pair blocks of diagonals d0 .. d0+nd-1
-void launch_pair_tail(const DeviceBatch& b, uint32_t d0, uint32_t nd, uint32_t max_n,
+void launch_pair_tail(const DeviceBatch& b, bool contra, uint32_t d0, uint32_t nd, uint32_t max_n,
                       uint32_t nseq, uint32_t block, hipStream_t st) {
   if (d0 >= max_n || nseq == 0 || nd == 0) return;
   const uint32_t bd = (max_n - d0 + block - 1) / block;
-  hipLaunchKernelGGL(k_pair_tail, dim3(nd * bd * nseq, 1, 1), dim3(block), 0, st, b, d0, bd, nseq);
+  const dim3 g(nd * bd * nseq, 1, 1);
+  if (contra) {
+    hipLaunchKernelGGL(k_pair_tail<true>, g, dim3(block), 0, st, b, d0, bd, nseq);
+  } else {
+    hipLaunchKernelGGL(k_pair_tail<false>, g, dim3(block), 0, st, b, d0, bd, nseq);
+  }
 }
 
 bool inside_is_split(uint32_t d, uint32_t max_n, uint32_t nseq) {

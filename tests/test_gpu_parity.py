@@ -408,16 +408,17 @@ def test_mccaskill_algo_returns_fold_scores(params, trnas):
         assert np.float32(v) == rac[bpp_index(n, i, j)]
 
 
-def test_two_diagonal_schedule_bit_exact(ctx, params):
-    """Large lock-step groups run the Turner inside sweep two diagonals per launch (folds of
-    d and d+1 off one operand stream, pair blocks split into an early and a last part).
+@pytest.mark.parametrize("contra,short", [(False, False), (True, False), (True, True)])
+def test_two_diagonal_schedule_bit_exact(ctx, params, contra, short):
+    """Large lock-step groups run the inside sweep two diagonals per launch (folds of d and
+    d+1 off one operand stream, pair blocks split into an early and a last part).
     Same bits as the oracle on a group big enough to take that schedule, and the same bits
     as the one-diagonal schedule on longer sequences."""
-    rng = np.random.default_rng(31)
+    rng = np.random.default_rng(31 + 2 * int(contra) + int(short))
     lens = rng.integers(180, 331, 420)
     seqs = [rng.integers(0, 4, int(n)).astype(np.uint8) for n in lens]
-    mats, logz = ctx.bpp_batch(seqs, False, False)
-    ref, ref_logz = O.bpp_batch(params.ptr, seqs, False, False, n_threads=16)
+    mats, logz = ctx.bpp_batch(seqs, contra, short)
+    ref, ref_logz = O.bpp_batch(params.ptr, seqs, contra, short, n_threads=16)
     for s, m, r in zip(seqs, mats, ref):
         assert_same(m.packed, r, f"n={len(s)}")
     assert np.array_equal(np.asarray(logz).view(np.uint32), np.asarray(ref_logz).view(np.uint32))
@@ -426,9 +427,9 @@ def test_two_diagonal_schedule_bit_exact(ctx, params):
     seqs = [rng.integers(0, 4, int(n)).astype(np.uint8) for n in lens]
     try:
         ctx.set("fuse_inside", 0)
-        one, logz1 = ctx.bpp_batch(seqs, False, False)
+        one, logz1 = ctx.bpp_batch(seqs, contra, short)
         ctx.set("fuse_inside", 1)
-        two, logz2 = ctx.bpp_batch(seqs, False, False)
+        two, logz2 = ctx.bpp_batch(seqs, contra, short)
     finally:
         ctx.set("fuse_inside", 1)
     for a, b in zip(one, two):
@@ -436,6 +437,6 @@ def test_two_diagonal_schedule_bit_exact(ctx, params):
     assert np.array_equal(np.asarray(logz1).view(np.uint32), np.asarray(logz2).view(np.uint32))
     # and one member of the second batch against the oracle
     k = int(np.argmax(lens))
-    r, rz = O.bpp(params.ptr, seqs[k], False, False)
+    r, rz = O.bpp(params.ptr, seqs[k], contra, short)
     assert_same(two[k].packed, r, "longest member")
     assert np.float32(logz2[k]).view(np.uint32) == np.float32(rz).view(np.uint32)
