@@ -52,6 +52,9 @@ struct rnamc_ctx {
   int64_t group_ws_bytes = 64ll << 30;
   int64_t block_threads = 256;
   int64_t profile = 0;
+  // dispatch order of the role blocks of a launch (measured: pair-probability chains first,
+  // probs_multibranch last is 2.5 % faster than the reverse; the inside order does not matter)
+  int64_t order_inside = 0, order_outside = 1;
   int64_t fuse_inside = 1;  // Turner: fold two diagonals per launch where launches are large
   int64_t debug_roles = 15;  // timing experiments only: bit0 folds, 1 pair block, 2 mb, 3 pair probs
   // bookkeeping of the last call
@@ -234,7 +237,8 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
     b.params = c->d_params;
     b.hp_init = c->d_hp_init;
     b.allows_short_hairpins = allows_short ? 1 : 0;
-    b.debug = static_cast<int>(c->debug_roles);
+    b.order_inside = static_cast<int>(c->order_inside);
+    b.order_outside = static_cast<int>(c->order_outside);
     // sequences with n > d form a prefix of the group
     auto active = [&](uint32_t d) {
       uint32_t lo = 0, hi = nseq;  // first index with n <= d
@@ -466,6 +470,10 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     c->block_threads = value;
   } else if (k == "profile") {
     c->profile = value;
+  } else if (k == "order_inside" && value >= 0 && value <= 2) {
+    c->order_inside = value;
+  } else if (k == "order_outside" && value >= 0 && value <= 4) {
+    c->order_outside = value;
   } else if (k == "fuse_inside") {
     c->fuse_inside = value;
   } else if (k == "debug_roles") {

@@ -21,7 +21,7 @@ struct DeviceBatch {
   const rnamc_params* params;
   const float* hp_init;     // Turner hairpin initiation by loop length (host-built)
   int allows_short_hairpins;
-  int debug;  // timing experiments only (rnamc_ctx_set "debug_roles" bits 4+)
+  int order_inside, order_outside;  // order in which a launch's role blocks are dispatched
 };
 
 void launch_init(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st);

@@ -884,10 +884,30 @@ __global__ void __launch_bounds__(256) k_inside2(DeviceBatch b, uint32_t d, uint
   __shared__ LseTab tabs;
   __shared__ ProbeTabs L;
   load_lse_table(&tabs);
-  const uint32_t bxr = blockIdx.x / nseq;
+  uint32_t bxr = blockIdx.x / nseq;
   const uint32_t which = blockIdx.x - bxr * nseq;
   const Seq q = load_seq(b, which);
   const uint32_t n = q.n;
+  if (do_head && !ZR_ONLY) {
+    // dispatch order (ctx knob order_inside): 0 = folds, heads; 1 = heads, folds;
+    // 2 = fold, head, head interleaved
+    const uint32_t mode = static_cast<uint32_t>(b.order_inside);
+    const uint32_t S = blocks_sums, H = 2u * blocks_head, p = bxr;
+    if (mode == 1u) {
+      bxr = (p < H) ? S + p : p - H;
+    } else if (mode == 2u) {
+      const uint32_t m = min(S, blocks_head);
+      if (p < 3u * m) {
+        const uint32_t r = p % 3u, x = p / 3u;
+        bxr = (r == 0u) ? x : (r == 1u ? S + x : S + blocks_head + x);
+      } else if (S > m) {
+        bxr = m + (p - 3u * m);
+      } else {
+        const uint32_t q2 = p - 3u * m, hh = blocks_head - m;
+        bxr = (q2 < hh) ? S + m + q2 : S + blocks_head + m + (q2 - hh);
+      }
+    }
+  }
   if (bxr < blocks_sums) {
     const uint32_t i = bxr * blockDim.x + threadIdx.x;
     if (!do_sums || d >= n || i >= n - d) return;
@@ -1029,7 +1049,7 @@ __device__ __forceinline__ void outside_pair_head(const DeviceBatch& b, const Se
   }
   // enclosing pairs (k,l) = (i-1-a, j+1+bb), a ascending (k descending), bb ascending,
   // a + bb <= 30, k >= 0, l <= n-1; rows with d+2+a > n-1 have no diagonal left
-  if (d + 2 < n && !(b.debug & 16)) {
+  if (d + 2 < n) {
     const uint32_t lim = min(static_cast<uint32_t>(RNAMC_MAX_2LOOP_LEN), n - 3 - d);
     p = probe_fold<CONTRA, true>(b, q, d, i, paired, lim, p, qb_ij, tab, L);
   }
@@ -1091,7 +1111,6 @@ __device__ __forceinline__ void outside_pair_tail(const DeviceBatch& b, const Se
   // so x is fetched for TWO chunks at a time (a line fetched in halves, microseconds
   // apart, is usually evicted in between and read twice from HBM).  Buffers: even chunks
   // use (xa, ya), odd chunks (xb, yb); xbn receives the odd half of the next pair.
-  if (b.debug & 32) imax_wave = 0;
   const uint32_t nch = (imax_wave + 15u) / 16u;
   if (nch) {
     float4 xa[4], xb[4], xbn[4], ya[8], yb[8];
@@ -1157,10 +1176,42 @@ __global__ void __launch_bounds__(256) k_outside(DeviceBatch b, uint32_t d, uint
   // linear id -> (role block, sequence) as in k_inside; within a role the blocks
   // with the longest walks are issued first (probs_multibranch: small i; pair
   // probabilities: large i)
-  const uint32_t bxr = blockIdx.x / nseq;
+  uint32_t bxr = blockIdx.x / nseq;
   const uint32_t which = blockIdx.x - bxr * nseq;
   const Seq q = load_seq(b, which);
   const uint32_t n = q.n;
+  {
+    // dispatch order (ctx knob order_outside): 0 = D, E, head; 1 = E, head, D;
+    // 2 = E and D interleaved, then head; 3 = head, then E/D interleaved; 4 = three-way
+    const uint32_t mode = static_cast<uint32_t>(b.order_outside);
+    const uint32_t B = blocks_mb, Bh = blocks_head;
+    const uint32_t p = bxr;
+    if (mode == 1u) {
+      if (p < B) bxr = B + p;
+      else if (p < B + Bh) bxr = 2u * B + (p - B);
+      else if (p < 2u * B + Bh) bxr = p - B - Bh;
+    } else if (mode == 2u) {
+      if (p < 2u * B) bxr = (p & 1u) ? B + (p >> 1) : (p >> 1);
+    } else if (mode == 3u) {
+      if (p < Bh) bxr = 2u * B + p;
+      else if (p < 2u * B + Bh) {
+        const uint32_t q2 = p - Bh;
+        bxr = (q2 & 1u) ? B + (q2 >> 1) : (q2 >> 1);
+      }
+    } else if (mode == 4u) {
+      const uint32_t m = min(B, Bh);
+      if (p < 3u * m) {
+        const uint32_t r = p % 3u, x = p / 3u;
+        bxr = (r == 0u) ? B + x : (r == 1u ? x : 2u * B + x);
+      } else if (B > Bh) {
+        const uint32_t q2 = p - 3u * m;
+        if (q2 < 2u * (B - m)) bxr = (q2 & 1u) ? B + m + (q2 >> 1) : m + (q2 >> 1);
+      } else {
+        const uint32_t q2 = p - 3u * m;
+        if (q2 < Bh - m) bxr = 2u * B + m + q2;
+      }
+    }
+  }
   if (bxr < blocks_mb) {
     if (!do_mb || d >= n) return;
     const uint32_t cells = n - d;

@@ -63,6 +63,10 @@ def main():
         ctx.set("debug_roles", int(os.environ["ROLES"]))
     if os.environ.get("WSGB"):
         ctx.set("group_ws_bytes", int(os.environ["WSGB"]) << 30)
+    if os.environ.get("ORDER_IN"):
+        ctx.set("order_inside", int(os.environ["ORDER_IN"]))
+    if os.environ.get("ORDER_OUT"):
+        ctx.set("order_outside", int(os.environ["ORDER_OUT"]))
     if os.environ.get("FUSE"):
         ctx.set("fuse_inside", int(os.environ["FUSE"]))
     if os.environ.get("BLOCK"):
@@ -84,6 +88,15 @@ def main():
             seqs = [WL.synthetic_seq(int(lens[s]), (10000 << 32) + int(s)) for s in order]
             ctx.set("group_max_seqs", cnt)
             run(ctx, seqs, False, reps=1, label=w)
+        elif w.startswith("bot"):
+            # the `cnt` shortest sequences of the 10k batch (2-loop work dominates there)
+            cnt = int(w[3:])
+            from rna_algos_amd import workloads as WL
+            lens = WL.batch_lengths(10000)
+            order = np.argsort(lens, kind="stable")[:cnt]
+            seqs = [WL.synthetic_seq(int(lens[s]), (10000 << 32) + int(s)) for s in order]
+            print("lengths", int(lens[order].min()), int(lens[order].max()))
+            run(ctx, seqs, False, reps=2, label=w)
         elif w.startswith("batch"):
             cnt = int(w[5:])
             lens = batch_lengths(10000)[:cnt]
