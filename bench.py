@@ -286,9 +286,15 @@ def main():
                 "launches_per_step": l_out // steps,
             },
             "roofline_inside": {
-                "kernel": "k_inside (inside sweep)", "bound": "hbm", "achieved": ach_in,
+                "kernel": "k_inside2 / k_inside (inside sweep)", "bound": "hbm", "achieved": ach_in,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_in / HBM_PEAK_GBS,
+                "traffic": pmc_traffic_per_launch(
+                    "k_inside", float(W.pair_cost(lens.astype(np.float64)).sum()), l_in / steps)
+                if args.workload == "batch10k" and not contra else None,
                 "avg_launch_ms": avg_in_ms, "launches_per_step": l_in // steps,
+                "note": "algorithmic bytes by the streamed-operand model (12 B per (cell,k)); the "
+                        "two-diagonal schedule folds two cells off one stream of the row operands, "
+                        "so the sweep moves about half of them",
             },
         }
         if args.workload != "batch10k":
