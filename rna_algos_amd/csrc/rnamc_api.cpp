@@ -45,6 +45,8 @@ struct rnamc_ctx {
   SeqDesc* d_seqs = nullptr;
   uint64_t seqs_cap = 0;
   hipStream_t own_stream = nullptr;
+  hipStream_t aux_stream = nullptr;           // pair tail of large outside launches
+  std::vector<hipEvent_t> ev_a, ev_b;         // per-diagonal completion, ring of 16
   std::recursive_mutex mu;  // rnamc_fold_scores re-enters rnamc_bpp_batch
   // knobs
   int64_t group_max_seqs = 8192;
@@ -55,6 +57,9 @@ struct rnamc_ctx {
   // dispatch order of the role blocks of a launch (measured: pair-probability chains first,
   // probs_multibranch last is 2.5 % faster than the reverse; the inside order does not matter)
   int64_t order_inside = 0, order_outside = 1;
+  int64_t dual_outside = 1;   // large outside launches: pair tail as its own kernel/stream
+  uint64_t dual_min_cells = 256 * 1024;
+  int64_t dual_max_diag = 1000;  // ... while the diagonal has at most this many cells
   int64_t fuse_inside = 1;  // Turner: fold two diagonals per launch where launches are large
   int64_t debug_roles = 15;  // timing experiments only: bit0 folds, 1 pair block, 2 mb, 3 pair probs
   // bookkeeping of the last call
@@ -308,13 +313,48 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
       }
     }
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 1], st));
-    // launch d carries the 2-loop half of diagonal d-1: start one diagonal early
-    for (uint32_t d = gmax + 1; d-- > dmin_out;) {
-      const bool head = d >= 1 && d - 1 >= dmin_out;
-      launch_outside(b, contra, d, gmax, active(d >= 1 ? d - 1 : 0), block,
-                     (c->debug_roles & 4) != 0, (c->debug_roles & 8) != 0,
-                     head && (c->debug_roles & 8) != 0, st);
-      c->stats.launches_outside++;
+    // Outside sweep.  Launch d carries probs_multibranch and the pair tail of diagonal d and
+    // the 2-loop half (pair head) of diagonal d-1: start one diagonal early.  Large launches
+    // run the pair tail as its own kernel on a second stream beside the other two roles
+    // (its register footprint would otherwise set their occupancy); both kernels of
+    // diagonal d need both kernels of diagonal d+1.
+    {
+      const bool r_mb = (c->debug_roles & 4) != 0, r_pp = (c->debug_roles & 8) != 0;
+      bool dual = false;  // the previous diagonal ran as two kernels
+      const uint32_t ring = static_cast<uint32_t>(c->ev_a.size());
+      for (uint32_t d = gmax + 1; d-- > dmin_out;) {
+        const bool head = d >= 1 && d - 1 >= dmin_out;
+        const uint32_t na = active(d >= 1 ? d - 1 : 0);
+        // worth it where the 2-loop blocks dominate a launch: the folds of a cell grow with
+        // the length of the diagonal, its 496 probes do not
+        const bool want_dual = c->dual_outside != 0 && d < gmax &&
+                               gmax - d <= static_cast<uint64_t>(c->dual_max_diag) &&
+                               static_cast<uint64_t>(gmax - d) * na >= c->dual_min_cells;
+        if (!want_dual) {
+          if (dual) {  // back to one stream: wait for the tail kernel of d+1
+            HIPCHK(hipStreamWaitEvent(st, c->ev_b[(d + 1) % ring], 0));
+            dual = false;
+          }
+          launch_outside(b, contra, d, gmax, na, block, r_mb, r_pp, head && r_pp, 7, st);
+          c->stats.launches_outside++;
+        } else {
+          hipEvent_t ea = c->ev_a[d % ring], eb = c->ev_b[d % ring];
+          if (!dual) {
+            // first two-kernel diagonal: everything so far is on `st`
+            HIPCHK(hipEventRecord(c->ev_a[(d + 1) % ring], st));
+          } else {
+            HIPCHK(hipStreamWaitEvent(st, c->ev_b[(d + 1) % ring], 0));
+          }
+          HIPCHK(hipStreamWaitEvent(c->aux_stream, c->ev_a[(d + 1) % ring], 0));
+          launch_outside(b, contra, d, gmax, na, block, r_mb, false, head && r_pp, 5, st);
+          HIPCHK(hipEventRecord(ea, st));
+          launch_outside(b, contra, d, gmax, na, block, false, r_pp, false, 2, c->aux_stream);
+          HIPCHK(hipEventRecord(eb, c->aux_stream));
+          c->stats.launches_outside += 2;
+          dual = true;
+        }
+      }
+      if (dual) HIPCHK(hipStreamWaitEvent(st, c->ev_b[dmin_out % ring], 0));
     }
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 2], st));
     launch_finalize(b, nseq, gmax, dmin_out, st);
@@ -433,6 +473,22 @@ int rnamc_ctx_create(const rnamc_params* params, int device, uint64_t workspace_
     return fail(RNAMC_ERR_HIP);
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess)
     return fail(RNAMC_ERR_HIP);
+  {
+    // the pair-tail kernel carries the longest dependent chains of a diagonal: its few
+    // workgroups should be placed first, the other kernel fills the rest of the chip
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, hi) != hipSuccess)
+      return fail(RNAMC_ERR_HIP);
+  }
+  for (int x = 0; x < 16; x++) {
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (hipEventCreateWithFlags(&ea, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&eb, hipEventDisableTiming) != hipSuccess)
+      return fail(RNAMC_ERR_HIP);
+    c->ev_a.push_back(ea);
+    c->ev_b.push_back(eb);
+  }
   if (workspace_bytes) {
     int rc = ensure_ws(c, workspace_bytes / 4);
     if (rc) return fail(rc);
@@ -447,6 +503,9 @@ void rnamc_ctx_destroy(rnamc_ctx* c) {
     DeviceGuard guard(c->device);
     (void)hipDeviceSynchronize();
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_a) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_b) (void)hipEventDestroy(e);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->d_hp_init) (void)hipFree(c->d_hp_init);
@@ -474,6 +533,12 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     c->order_inside = value;
   } else if (k == "order_outside" && value >= 0 && value <= 4) {
     c->order_outside = value;
+  } else if (k == "dual_outside") {
+    c->dual_outside = value;
+  } else if (k == "dual_max_diag" && value >= 0) {
+    c->dual_max_diag = value;
+  } else if (k == "dual_min_cells" && value >= 0) {
+    c->dual_min_cells = static_cast<uint64_t>(value);
   } else if (k == "fuse_inside") {
     c->fuse_inside = value;
   } else if (k == "debug_roles") {

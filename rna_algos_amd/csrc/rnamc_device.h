@@ -41,8 +41,10 @@ void launch_pair_tail(const DeviceBatch& b, bool contra, uint32_t d0, uint32_t n
                       uint32_t nseq, uint32_t block, hipStream_t st);
 // true when the folds of diagonal d run in the latency form (launch too small to fill the chip)
 bool inside_is_split(uint32_t d, uint32_t max_n, uint32_t nseq);
+// roles: 7 = all three roles in one kernel; 5 = probs_multibranch + pair head; 2 = pair tail
 void launch_outside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
-                    uint32_t block, bool do_mb, bool do_tail, bool do_head, hipStream_t st);
+                    uint32_t block, bool do_mb, bool do_tail, bool do_head, int roles,
+                    hipStream_t st);
 void launch_finalize(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, uint32_t dmin_out,
                      hipStream_t st);
 

@@ -1165,8 +1165,14 @@ __device__ __forceinline__ void outside_pair_tail(const DeviceBatch& b, const Se
 // probs_multibranch{,2} of diagonal d, the multibranch half of the pair
 // probabilities of diagonal d, and the 2-loop half of diagonal d-1 (which the
 // next launch continues).  All read only results of longer spans.
-template <bool CONTRA>
-__global__ void __launch_bounds__(256) k_outside(DeviceBatch b, uint32_t d, uint32_t blocks_mb,
+// ROLES (compile time): bit 0 probs_multibranch, bit 1 pair tail, bit 2 pair head.  The pair
+// tail keeps whole cache lines of three columns in registers; compiled into one kernel it
+// sets the occupancy of the other two roles as well, so large launches run it as a kernel
+// of its own on a second stream (ROLES = 2 beside ROLES = 5) and only small launches use
+// the all-in-one form (ROLES = 7).
+template <bool CONTRA, int ROLES>
+__global__ void __launch_bounds__(256)
+    __attribute__((amdgpu_waves_per_eu(ROLES == 5 ? 4 : 1, 8))) k_outside(DeviceBatch b, uint32_t d, uint32_t blocks_mb,
                                                  uint32_t blocks_head, uint32_t nseq, int do_mb,
                                                  int do_tail, int do_head) {
   __shared__ LseTab tabs;
@@ -1213,16 +1219,19 @@ __global__ void __launch_bounds__(256) k_outside(DeviceBatch b, uint32_t d, uint
     }
   }
   if (bxr < blocks_mb) {
-    if (!do_mb || d >= n) return;
+    if (!(ROLES & 1) || !do_mb || d >= n) return;
     const uint32_t cells = n - d;
     const uint32_t i = bxr * blockDim.x + threadIdx.x;
     const uint32_t wave_first = i - (threadIdx.x & 63u);  // lane 0 of this wave
     if (wave_first >= cells) return;                       // whole wave has no cell
     // the first lane of the wave has the longest walk: n-1-j with j = i+d
-    const uint32_t cnt_wave = n - 1 - d - wave_first;
+    // (readfirstlane: the value is wave-uniform, but derived from threadIdx the compiler
+    // would keep the loop control and the diagonal offsets of the walk in vector registers)
+    const uint32_t cnt_wave = static_cast<uint32_t>(
+        __builtin_amdgcn_readfirstlane(static_cast<int>(n - 1 - d - wave_first)));
     outside_mb_cell<CONTRA>(b, q, d, i, i < cells, cnt_wave, tab);
   } else if (bxr < 2u * blocks_mb) {
-    if (!do_tail || d >= n) return;
+    if (!(ROLES & 2) || !do_tail || d >= n) return;
     const uint32_t cnt = q.ccnt[d];
     const uint32_t bx = 2u * blocks_mb - 1u - bxr;  // descending: heavy blocks first
     if (bx * blockDim.x >= cnt) return;            // block past the list (uniform)
@@ -1233,10 +1242,11 @@ __global__ void __launch_bounds__(256) k_outside(DeviceBatch b, uint32_t d, uint
     const bool valid = listed_cell(q, d, t, cnt, i);
     // the last listed lane of the wave has the largest i, i.e. the longest walk
     const uint32_t last_lane = min(63u, cnt - 1u - wave_first);
-    const uint32_t imax = static_cast<uint32_t>(__shfl(static_cast<int>(i), static_cast<int>(last_lane)));
+    const uint32_t imax = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
+        __shfl(static_cast<int>(i), static_cast<int>(last_lane))));
     outside_pair_tail<CONTRA>(b, q, d, i, valid, imax, tab);
   } else {
-    if (!do_head || d == 0 || d - 1 >= n) return;
+    if (!(ROLES & 4) || !do_head || d == 0 || d - 1 >= n) return;
     const uint32_t dh = d - 1;
     const uint32_t cnt = q.ccnt[dh];
     const uint32_t bx = bxr - 2u * blocks_mb;
@@ -1364,19 +1374,26 @@ bool inside_is_split(uint32_t d, uint32_t max_n, uint32_t nseq) {
 // launch of diagonal d: probs_multibranch (do_mb) and multibranch half of the pair
 // probabilities (do_tail) of diagonal d, 2-loop half (do_head) of diagonal d-1
 void launch_outside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
-                    uint32_t block, bool do_mb, bool do_tail, bool do_head, hipStream_t st) {
+                    uint32_t block, bool do_mb, bool do_tail, bool do_head, int roles,
+                    hipStream_t st) {
   if (nseq == 0) return;
   const uint32_t nb = d < max_n ? (max_n - d + block - 1) / block : 0;
   const uint32_t nh = (do_head && d >= 1 && d - 1 < max_n) ? (max_n - d + 1 + block - 1) / block : 0;
   if (2 * nb + nh == 0) return;
   const dim3 g((2 * nb + nh) * nseq, 1, 1);
+  const int a0 = do_mb ? 1 : 0, a1 = do_tail ? 1 : 0, a2 = do_head ? 1 : 0;
+#define RNAMC_LAUNCH_OUT(C, R) \
+  hipLaunchKernelGGL((k_outside<C, R>), g, dim3(block), 0, st, b, d, nb, nh, nseq, a0, a1, a2)
   if (contra) {
-    hipLaunchKernelGGL(k_outside<true>, g, dim3(block), 0, st, b, d, nb, nh, nseq, do_mb ? 1 : 0,
-                       do_tail ? 1 : 0, do_head ? 1 : 0);
+    if (roles == 5) RNAMC_LAUNCH_OUT(true, 5);
+    else if (roles == 2) RNAMC_LAUNCH_OUT(true, 2);
+    else RNAMC_LAUNCH_OUT(true, 7);
   } else {
-    hipLaunchKernelGGL(k_outside<false>, g, dim3(block), 0, st, b, d, nb, nh, nseq, do_mb ? 1 : 0,
-                       do_tail ? 1 : 0, do_head ? 1 : 0);
+    if (roles == 5) RNAMC_LAUNCH_OUT(false, 5);
+    else if (roles == 2) RNAMC_LAUNCH_OUT(false, 2);
+    else RNAMC_LAUNCH_OUT(false, 7);
   }
+#undef RNAMC_LAUNCH_OUT
 }
 
 void launch_finalize(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, uint32_t dmin_out,

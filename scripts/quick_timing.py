@@ -67,6 +67,12 @@ def main():
         ctx.set("order_inside", int(os.environ["ORDER_IN"]))
     if os.environ.get("ORDER_OUT"):
         ctx.set("order_outside", int(os.environ["ORDER_OUT"]))
+    if os.environ.get("DUAL"):
+        ctx.set("dual_outside", int(os.environ["DUAL"]))
+    if os.environ.get("DUALDIAG"):
+        ctx.set("dual_max_diag", int(os.environ["DUALDIAG"]))
+    if os.environ.get("DUALMIN"):
+        ctx.set("dual_min_cells", int(os.environ["DUALMIN"]))
     if os.environ.get("FUSE"):
         ctx.set("fuse_inside", int(os.environ["FUSE"]))
     if os.environ.get("BLOCK"):
