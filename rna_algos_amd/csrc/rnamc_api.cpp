@@ -59,7 +59,7 @@ struct rnamc_ctx {
   int64_t order_inside = 0, order_outside = 1;
   int64_t dual_outside = 1;   // large outside launches: pair tail as its own kernel/stream
   uint64_t dual_min_cells = 256 * 1024;
-  int64_t dual_max_diag = 1000;  // ... while the diagonal has at most this many cells
+  int64_t dual_max_diag = 1 << 30;  // ... while the diagonal has at most this many cells
   int64_t fuse_inside = 1;  // Turner: fold two diagonals per launch where launches are large
   int64_t debug_roles = 15;  // timing experiments only: bit0 folds, 1 pair block, 2 mb, 3 pair probs
   // bookkeeping of the last call
@@ -168,7 +168,10 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
       const uint64_t pk_words = ((static_cast<uint64_t>(n) + 160) / 16 + 4 + 63) & ~63ull;
       const uint64_t cidx_words = (tri_pad_of(n) + 1) / 2;  // u16 per cell, in 4-byte units
       const uint64_t ccnt_words = (static_cast<uint64_t>(n) + 63) & ~63ull;
-      const uint64_t need = tri_pad_of(n) * M_COUNT + pk_words + cidx_words + ccnt_words;
+      const uint64_t c64_words =
+          ((static_cast<uint64_t>(n) + 63) / 64 * (static_cast<uint64_t>(n) + 64) + 63) & ~63ull;
+      const uint64_t need =
+          tri_pad_of(n) * M_COUNT + pk_words + cidx_words + ccnt_words + c64_words;
       // a launch should carry enough cells to fill the chip: short sequences go into
       // larger groups (bounded by nucleotides, sequences and workspace bytes)
       if (cnt > 0 && (cnt >= static_cast<uint32_t>(c->group_max_seqs) ||
@@ -191,6 +194,7 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
       sd.pk_off = cur + tri_pad_of(n) * M_COUNT;
       sd.cidx_off = sd.pk_off + pk_words;
       sd.ccnt_off = sd.cidx_off + cidx_words;
+      sd.c64_off = sd.ccnt_off + ccnt_words;
       c->descs.push_back(sd);
       cur += need;
       cur_nt += n;

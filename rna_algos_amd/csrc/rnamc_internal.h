@@ -47,6 +47,8 @@ struct SeqDesc {
   uint64_t pk_off;    // float offset of that copy in the workspace
   uint64_t cidx_off;  // float offset of the u16 lists of canonical cells (one per diagonal)
   uint64_t ccnt_off;  // float offset of the u32 list lengths (one per diagonal)
+  uint64_t c64_off;   // float offset of the u32 table: canonical cells before position 64*w
+                      // of diagonal D at [w * (n + 64) + D]
 };
 
 }  // namespace rnamc

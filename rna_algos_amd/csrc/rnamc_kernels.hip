@@ -231,6 +231,8 @@ struct Seq {
   // canonical-pair cells of every diagonal, ascending i, at tri_off(n,d); counts per d
   uint16_t* cidx;
   uint32_t* ccnt;
+  // c64[w * (n + 64) + D]: canonical cells of diagonal D at positions < 64 w (0 for D >= n)
+  uint32_t* c64;
 };
 
 __device__ __forceinline__ Seq load_seq(const DeviceBatch& b, uint32_t which) {
@@ -245,6 +247,7 @@ __device__ __forceinline__ Seq load_seq(const DeviceBatch& b, uint32_t which) {
   q.pk = reinterpret_cast<const uint32_t*>(b.workspace + sd.pk_off);
   q.cidx = reinterpret_cast<uint16_t*>(b.workspace + sd.cidx_off);
   q.ccnt = reinterpret_cast<uint32_t*>(b.workspace + sd.ccnt_off);
+  q.c64 = reinterpret_cast<uint32_t*>(b.workspace + sd.c64_off);
   return q;
 }
 
@@ -345,15 +348,22 @@ __global__ void __launch_bounds__(64) k_compact(DeviceBatch b) {
   const uint8_t* s = q.s;
   uint16_t* dst = q.cidx + tri_off(n, d);
   const uint32_t lane = threadIdx.x;
+  const uint32_t stride = n + 64u, nb64 = (n + 63u) / 64u;
   uint32_t cnt = 0;
   for (uint32_t i0 = 0; i0 < n - d; i0 += 64) {
     const uint32_t i = i0 + lane;
     const bool c = (i < n - d) && canonical(s[i], s[i + d]);
     const unsigned long long m = __ballot(c);
+    if (lane == 0) q.c64[(i0 >> 6) * stride + d] = cnt;
     if (c) dst[cnt + __popcll(m & ((1ull << lane) - 1ull))] = static_cast<uint16_t>(i);
     cnt += static_cast<uint32_t>(__popcll(m));
   }
   if (lane == 0) q.ccnt[d] = cnt;
+  // 64-blocks past the end of this diagonal, and the columns D >= n that a chunked walk
+  // may touch: every entry of the table is defined
+  for (uint32_t w = (n - d + 63u) / 64u + lane; w < nb64; w += 64) q.c64[w * stride + d] = cnt;
+  if (d == 0)
+    for (uint32_t x = lane; x < nb64 * 64u; x += 64) q.c64[(x >> 6) * stride + n + (x & 63u)] = 0u;
 }
 
 // lane -> listed cell of diagonal d; returns false for lanes past the list
@@ -971,14 +981,19 @@ __device__ __forceinline__ void outside_mb_cell(const DeviceBatch& b, const Seq&
   const uint32_t j = i + d;
   const float* __restrict__ q1d = q.m[M_Q1D];
   const float* __restrict__ w = q.m[M_W];
+  const uint32_t* __restrict__ pk = q.pk;
+  // W is stored for canonical cells only (62 % of a diagonal is no pair): cell (i,k) of
+  // diagonal D = k-i sits at list index c64[i/64][D] + (canonical cells of this wave's
+  // lanes before this one), which is a ballot away — the bases come from the 2-bit copy
+  const uint32_t* __restrict__ c64row =
+      q.c64 + static_cast<size_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(i >> 6))) * (n + 64u);
   const float mun = CONTRA ? b.params->contra.multibranch_score_unpair : 0.f;
   const uint32_t cnt = valid ? n - 1 - j : 0u;  // this lane's trip count
   const uint32_t i4 = i * 4u;
+  // partners of base a as a 4-bit set: A:{U} C:{G} G:{C,U} U:{A,G}
+  const uint32_t pairmask = valid ? (0x5A48u >> (4u * q.s[i])) & 15u : 0u;
   float pm = kNegInf, pm2 = kNegInf;
-  // W(i,k): diagonal d+t, offset i (-inf when (i,k) is no pair);
-  // sums_1ormore_basepairs[j+1][k-1]: diagonal t-2, offset j+1
   auto step = [&](float x, float r, uint32_t t) {
-    x = (t <= cnt) ? x : kNegInf;  // past this lane's row end
     pm = lse(pm, x + r, tab);
     if (CONTRA) {
       pm2 = lse(pm2, x + mun * static_cast<float>(t - 1), tab);
@@ -986,34 +1001,100 @@ __device__ __forceinline__ void outside_mb_cell(const DeviceBatch& b, const Seq&
       pm2 = lse(pm2, x, tab);
     }
   };
+  struct DAux {
+    uint32_t t0;        // first step of the chunk
+    uint32_t win;       // bases k = j+t0 .. j+t0+15, 2 bits each
+    uint32_t base[kU];  // c64 of diagonals d+t0 .. d+t0+kU-1
+  };
+  struct DOps {
+    float xs[kU], rs[kU];
+    uint32_t bits;
+  };
+  auto load_aux = [&](DAux& A, uint32_t t0) {
+    A.t0 = t0;
+    const uint32_t bit = 2u * (j + t0 + 32u);
+    const uint32_t wd = bit >> 5, sh = bit & 31u;
+    A.win = __builtin_amdgcn_alignbit(pk[wd + 1], pk[wd], sh);
+#pragma unroll
+    for (int u = 0; u < kU; u++) A.base[u] = c64row[d + t0 + u];
+  };
+  auto locate = [&](uint32_t win, uint32_t u, uint32_t t, uint32_t base, bool& has) {
+    const uint32_t c = (win >> (2u * u)) & 3u;
+    has = (((pairmask >> c) & 1u) != 0u) && (t <= cnt);
+    const unsigned long long m = __ballot(has);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(
+        static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+    return (base + rank) * 4u;
+  };
+  auto issue = [&](DOps& B, const DAux& A) {
+    const uint32_t t0 = A.t0;
+    uint32_t bits = 0;
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      bool has;
+      const uint32_t off = locate(A.win, u, t0 + u, A.base[u], has);
+      B.xs[u] = ldu(w + tri_off(n, d + t0 + u), off);
+      B.rs[u] = ldu(q1d + tri_off(n, t0 + u - 2) + d + 1, i4);
+      bits |= (has ? 1u : 0u) << u;
+    }
+    B.bits = bits;
+  };
+  auto fold = [&](const DOps& B, uint32_t t0) {
+#pragma unroll
+    for (int u = 0; u < kU; u++)
+      step(((B.bits >> u) & 1u) ? B.xs[u] : kNegInf, B.rs[u], t0 + u);
+  };
+  auto single = [&](uint32_t t, float& x) {  // one step outside the pipeline
+    const uint32_t bit = 2u * (j + t + 32u);
+    const uint32_t wd = bit >> 5, sh = bit & 31u;
+    const uint32_t win = __builtin_amdgcn_alignbit(pk[wd + 1], pk[wd], sh);
+    bool has;
+    const uint32_t off = locate(win, 0u, t, c64row[d + t], has);
+    const float v = ldu(w + tri_off(n, d + t), off);
+    x = has ? v : kNegInf;
+  };
   if (cnt_wave >= 1) {
     // t = 1: sums_1ormore_basepairs[j+1][j] is the empty interval (-inf): only pm2 moves
-    const float x1 = (1u <= cnt) ? ldu(w + tri_off(n, d + 1), i4) : kNegInf;
+    float x1;
+    single(1u, x1);
     if (CONTRA) {
       pm2 = lse(pm2, x1 + mun * 0.f, tab);
     } else {
       pm2 = lse(pm2, x1, tab);
     }
   }
-  struct DBuf {
-    float xs[kU], rs[kU];
-  };
-  // steps 2 .. cnt_wave
-  uint32_t t = pingpong<DBuf>(
-      2u, cnt_wave >= 2 ? (cnt_wave - 1) / kU : 0u,
-      [&](DBuf& B, uint32_t t0) {
-#pragma unroll
-        for (int u = 0; u < kU; u++) {
-          B.xs[u] = ldu(w + tri_off(n, d + t0 + u), i4);
-          B.rs[u] = ldu(q1d + tri_off(n, t0 + u - 2) + d + 1, i4);
-        }
-      },
-      [&](const DBuf& B, uint32_t t0) {
-#pragma unroll
-        for (int u = 0; u < kU; u++) step(B.xs[u], B.rs[u], t0 + u);
-      });
-  for (; t <= cnt_wave; t++)
-    step(ldu(w + tri_off(n, d + t), i4), ldu(q1d + tri_off(n, t - 2) + d + 1, i4), t);
+  // steps 2 .. cnt_wave in chunks of kU, three stages deep: the window / c64 entries of
+  // chunk c+2 and the operands of chunk c+1 are in flight while chunk c is folded.  Every
+  // stage runs unconditionally (past the last chunk it re-fetches the last chunk), so the
+  // number of loads in flight at each wait is static.
+  uint32_t t = 2u;
+  const uint32_t nch = cnt_wave >= 2 ? (cnt_wave - 1) / kU : 0u;
+  if (nch) {
+    const uint32_t t_last = 2u + (nch - 1u) * kU;
+    DAux xa, xb;
+    DOps oa, ob;
+    load_aux(xa, t);
+    load_aux(xb, min(t + kU, t_last));
+    issue(oa, xa);
+    uint32_t c = 0;
+    for (;;) {
+      load_aux(xa, min(t + 2 * kU, t_last));
+      issue(ob, xb);
+      fold(oa, t);
+      t += kU;
+      if (++c >= nch) break;
+      load_aux(xb, min(t + 2 * kU, t_last));
+      issue(oa, xa);
+      fold(ob, t);
+      t += kU;
+      if (++c >= nch) break;
+    }
+  }
+  for (; t <= cnt_wave; t++) {
+    float x;
+    single(t, x);
+    step(x, ldu(q1d + tri_off(n, t - 2) + d + 1, i4), t);
+  }
   if (valid) {
     // {probs_multibranch, probs_multibranch2} interleaved: 16 k-steps of a column = one
     // 128-byte line (slots PM and PM2 are adjacent and form one float2 array)
@@ -1063,8 +1144,8 @@ __device__ __forceinline__ void outside_pair_head(const DeviceBatch& b, const Se
 // A lane that is no pair, or is past its own i, folds -inf terms (no-ops).
 template <bool CONTRA>
 __device__ __forceinline__ void outside_pair_tail(const DeviceBatch& b, const Seq& q, uint32_t d,
-                                                  uint32_t i, bool valid, uint32_t imax_wave,
-                                                  const LseTab* tab) {
+                                                  uint32_t i, uint32_t tl, bool valid,
+                                                  uint32_t imax_wave, const LseTab* tab) {
   const uint32_t n = q.n;
   const uint32_t od = tri_off(n, d) + i;
   const float qb_ij = valid ? q.m[M_QB][od] : kNegInf;
@@ -1157,7 +1238,7 @@ __device__ __forceinline__ void outside_pair_tail(const DeviceBatch& b, const Se
   }
   if (paired && p > kNegInf) {
     q.m[M_P][od] = p;
-    q.m[M_W][od] = p + q.m[M_MBC][od] - qb_ij;
+    q.m[M_W][tri_off(n, d) + tl] = p + q.m[M_MBC][od] - qb_ij;  // list index, see outside_mb_cell
   }
 }
 
@@ -1244,7 +1325,7 @@ __global__ void __launch_bounds__(256)
     const uint32_t last_lane = min(63u, cnt - 1u - wave_first);
     const uint32_t imax = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
         __shfl(static_cast<int>(i), static_cast<int>(last_lane))));
-    outside_pair_tail<CONTRA>(b, q, d, i, valid, imax, tab);
+    outside_pair_tail<CONTRA>(b, q, d, i, t, valid, imax, tab);
   } else {
     if (!(ROLES & 4) || !do_head || d == 0 || d - 1 >= n) return;
     const uint32_t dh = d - 1;
