@@ -1188,25 +1188,15 @@ __device__ __forceinline__ void outside_pair_tail(const DeviceBatch& b, const Se
     }
     p = lse(p, sa + x + y, tab);
   };
-  // Chunks of 16 k-steps.  A 128-byte line holds 16 steps of {y, y2} but 32 steps of x,
-  // so x is fetched for TWO chunks at a time (a line fetched in halves, microseconds
-  // apart, is usually evicted in between and read twice from HBM).  Buffers: even chunks
-  // use (xa, ya), odd chunks (xb, yb); xbn receives the odd half of the next pair.
+  // Chunks of 16 k-steps.  A 128-byte line holds 16 steps of {y, y2} and 32 steps of x; a
+  // lane fetches whole lines of its own columns (64-byte pieces read 11 % slower) into ONE
+  // buffer per stream (64 VGPRs).  Double-buffering them (112 VGPRs, 3 waves per SIMD) was
+  // 12 % slower over the whole outside sweep: the other waves of the SIMD hide the fetch
+  // latency better than a deeper pipeline that starves every role of registers.
   const uint32_t nch = (imax_wave + 15u) / 16u;
   if (nch) {
-    float4 xa[4], xb[4], xbn[4], ya[8], yb[8];
-    auto ld_x32 = [&](uint32_t k0, float4(&lo)[4], float4(&hi)[4]) {
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        lo[u] = xcol[k0 / 4 + u];
-        hi[u] = xcol[k0 / 4 + 4 + u];
-      }
-    };
-    auto ld_y16 = [&](uint32_t k0, float4(&y)[8]) {
-#pragma unroll
-      for (int u = 0; u < 8; u++) y[u] = yycol[k0 / 2 + u];
-    };
-    auto fold16 = [&](const float4(&x)[4], const float4(&y)[8], uint32_t k0) {
+    float4 xl[8], yl[8];
+    auto fold16l = [&](const float4* x, const float4(&y)[8], uint32_t k0) {
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         step(x[u].x, y[2 * u].x, y[2 * u].y, k0 + 4 * u);
@@ -1215,25 +1205,14 @@ __device__ __forceinline__ void outside_pair_tail(const DeviceBatch& b, const Se
         step(x[u].w, y[2 * u + 1].z, y[2 * u + 1].w, k0 + 4 * u + 3);
       }
     };
-    ld_x32(0, xa, xb);
-    ld_y16(0, ya);
-    uint32_t c = 0, k = 0;
-    for (;;) {
-      if (c + 1 < nch) ld_y16(k + 16, yb);
-      fold16(xa, ya, k);
-      k += 16;
-      c++;
-      if (c >= nch) break;
-      if (c + 1 < nch) {
-        ld_x32(k + 16, xa, xbn);
-        ld_y16(k + 16, ya);
-      }
-      fold16(xb, yb, k);
-      k += 16;
-      c++;
-      if (c >= nch) break;
+    for (uint32_t c = 0, k = 0; c < nch; c++, k += 16) {
+      if ((c & 1u) == 0u) {
 #pragma unroll
-      for (int u = 0; u < 4; u++) xb[u] = xbn[u];
+        for (int u = 0; u < 8; u++) xl[u] = xcol[k / 4 + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) yl[u] = yycol[k / 2 + u];
+      if ((c & 1u) == 0u) fold16l(&xl[0], yl, k); else fold16l(&xl[4], yl, k);
     }
   }
   if (paired && p > kNegInf) {
