@@ -233,12 +233,20 @@ int rnamc_bpp_batch_device(rnamc_ctx* ctx, uint32_t n_seqs, const uint8_t* d_bas
 typedef struct rnamc_batch_stats {
   uint64_t n_groups;
   uint64_t launches_inside;
-  uint64_t launches_outside;
+  uint64_t launches_outside;  /* kernels of the outside sweeps (two per diagonal on large launches) */
   uint64_t launches_other;
   double ms_inside;   /* sum of event-timed inside sweeps  */
   double ms_outside;  /* sum of event-timed outside sweeps */
   double ms_other;
   uint64_t workspace_bytes;
+  /* per-kernel accounting of the outside sweep (rnamc_ctx_set(ctx,"profile",2) only; the
+   * extra event records cost about 2 % of the sweep): launches and summed
+   * durations (HIP events around every launch, on the stream it is launched on) of
+   *   main : k_outside<.,5>  probs_multibranch + 2-loop half of the pair probabilities
+   *   tail : k_outside<.,2>  multibranch half of the pair probabilities (second stream)
+   *   small: k_outside<.,7>  all three roles in one kernel (launches too small to split) */
+  uint64_t launches_outside_main, launches_outside_tail, launches_outside_small;
+  double ms_outside_main, ms_outside_tail, ms_outside_small;
 } rnamc_batch_stats;
 int rnamc_ctx_last_stats(rnamc_ctx* ctx, rnamc_batch_stats* out);
 

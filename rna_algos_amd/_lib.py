@@ -42,6 +42,10 @@ class BatchStats(C.Structure):
         ("launches_outside", C.c_uint64), ("launches_other", C.c_uint64),
         ("ms_inside", C.c_double), ("ms_outside", C.c_double), ("ms_other", C.c_double),
         ("workspace_bytes", C.c_uint64),
+        ("launches_outside_main", C.c_uint64), ("launches_outside_tail", C.c_uint64),
+        ("launches_outside_small", C.c_uint64),
+        ("ms_outside_main", C.c_double), ("ms_outside_tail", C.c_double),
+        ("ms_outside_small", C.c_double),
     ]
 
 

@@ -67,6 +67,8 @@ struct rnamc_ctx {
   std::vector<SeqDesc> descs;       // all groups, group-major
   std::vector<uint32_t> group_begin;  // prefix into descs
   std::vector<hipEvent_t> events;
+  std::vector<hipEvent_t> kev;        // per-launch event pairs of the outside kernels (profiling)
+  std::vector<uint8_t> kev_class;     // 0 main, 1 tail, 2 small; one per pair
 };
 
 namespace {
@@ -136,6 +138,7 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
               bool contra, bool allows_short, float* d_out, const uint64_t* out_offsets,
               float* d_logz, hipStream_t st) {
   c->stats = rnamc_batch_stats{};
+  c->kev_class.clear();
   c->descs.clear();
   c->group_begin.clear();
   if (n_seqs == 0) return RNAMC_OK;
@@ -325,6 +328,26 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
     {
       const bool r_mb = (c->debug_roles & 4) != 0, r_pp = (c->debug_roles & 8) != 0;
       bool dual = false;  // the previous diagonal ran as two kernels
+      // profiling: a pair of events around every kernel, on the stream it is launched on
+      auto timed = [&](uint8_t cls, hipStream_t s, auto&& launch) {
+        if (c->profile < 2) {
+          launch();
+          return;
+        }
+        const size_t x = c->kev_class.size();
+        while (c->kev.size() < 2 * (x + 1)) {
+          hipEvent_t e = nullptr;
+          if (hipEventCreate(&e) != hipSuccess) {  // out of events: stop timing, keep running
+            launch();
+            return;
+          }
+          c->kev.push_back(e);
+        }
+        (void)hipEventRecord(c->kev[2 * x], s);
+        launch();
+        (void)hipEventRecord(c->kev[2 * x + 1], s);
+        c->kev_class.push_back(cls);
+      };
       const uint32_t ring = static_cast<uint32_t>(c->ev_a.size());
       for (uint32_t d = gmax + 1; d-- > dmin_out;) {
         const bool head = d >= 1 && d - 1 >= dmin_out;
@@ -339,7 +362,9 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
             HIPCHK(hipStreamWaitEvent(st, c->ev_b[(d + 1) % ring], 0));
             dual = false;
           }
-          launch_outside(b, contra, d, gmax, na, block, r_mb, r_pp, head && r_pp, 7, st);
+          timed(2, st, [&]() {
+            launch_outside(b, contra, d, gmax, na, block, r_mb, r_pp, head && r_pp, 7, st);
+          });
           c->stats.launches_outside++;
         } else {
           hipEvent_t ea = c->ev_a[d % ring], eb = c->ev_b[d % ring];
@@ -350,9 +375,13 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
             HIPCHK(hipStreamWaitEvent(st, c->ev_b[(d + 1) % ring], 0));
           }
           HIPCHK(hipStreamWaitEvent(c->aux_stream, c->ev_a[(d + 1) % ring], 0));
-          launch_outside(b, contra, d, gmax, na, block, r_mb, false, head && r_pp, 5, st);
+          timed(0, st, [&]() {
+            launch_outside(b, contra, d, gmax, na, block, r_mb, false, head && r_pp, 5, st);
+          });
           HIPCHK(hipEventRecord(ea, st));
-          launch_outside(b, contra, d, gmax, na, block, false, r_pp, false, 2, c->aux_stream);
+          timed(1, c->aux_stream, [&]() {
+            launch_outside(b, contra, d, gmax, na, block, false, r_pp, false, 2, c->aux_stream);
+          });
           HIPCHK(hipEventRecord(eb, c->aux_stream));
           c->stats.launches_outside += 2;
           dual = true;
@@ -378,6 +407,20 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
       c->stats.ms_inside += a;
       c->stats.ms_outside += bms;
       c->stats.ms_other += cc;
+    }
+    for (size_t x = 0; x < c->kev_class.size(); x++) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, c->kev[2 * x], c->kev[2 * x + 1]) != hipSuccess) continue;
+      if (c->kev_class[x] == 0) {
+        c->stats.ms_outside_main += ms;
+        c->stats.launches_outside_main++;
+      } else if (c->kev_class[x] == 1) {
+        c->stats.ms_outside_tail += ms;
+        c->stats.launches_outside_tail++;
+      } else {
+        c->stats.ms_outside_small += ms;
+        c->stats.launches_outside_small++;
+      }
     }
   }
   return RNAMC_OK;
@@ -507,6 +550,7 @@ void rnamc_ctx_destroy(rnamc_ctx* c) {
     DeviceGuard guard(c->device);
     (void)hipDeviceSynchronize();
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_a) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_b) (void)hipEventDestroy(e);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);

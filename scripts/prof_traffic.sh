@@ -18,18 +18,24 @@ n = collections.defaultdict(int)
 for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         kn = r["Kernel_Name"]
-        k = "k_outside" if "k_outside" in kn else "k_inside" if "k_inside" in kn else "other"
+        if "k_outside" in kn:
+            k = "k_outside_main" if ", 5>" in kn else "k_outside_tail" if ", 2>" in kn else "k_outside_small"
+        elif "k_inside" in kn or "k_pair_tail" in kn:
+            k = "k_inside"
+        else:
+            k = "other"
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] == "FETCH_SIZE": n[k] += 1
 b = json.loads(open(out + "/bench_FETCH_SIZE.json").read().strip().splitlines()[-1])
 res = {"bench_config": b["config"], "launches": dict(n), "counters_KB": {k: dict(v) for k, v in agg.items()}}
-for k in ("k_inside", "k_outside"):
+for k in ("k_inside", "k_outside_main", "k_outside_tail", "k_outside_small"):
     f, w = agg[k]["FETCH_SIZE"] * 1024, agg[k]["WRITE_SIZE"] * 1024
-    # gfx950: FETCH_SIZE tallies 128-B requests at 64 B for wide streaming reads (guide §HBM);
-    # our reads are 4 B/lane (256 B per wave): uncalibrated, both readings are given
+    # gfx950: FETCH_SIZE tallies 128-B requests at 64 B (guide §HBM); calibrated on our own
+    # access patterns in profiles/r01_fetch_size_calibration.txt: 0.50 x bytes for all of them
     res[k] = {"fetch_bytes_raw": f, "fetch_bytes_x2": 2 * f, "write_bytes": w, "launches": n[k],
               "per_launch_raw": (f + w) / max(n[k], 1), "per_launch_x2": (2 * f + w) / max(n[k], 1)}
-res["roofline"] = b["roofline"]; res["roofline_inside"] = b["roofline_inside"]
+for key in ("roofline", "roofline_tail", "roofline_outside_sweep", "roofline_inside"):
+    if key in b: res[key] = b[key]
 json.dump(res, open(out + "/traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1)[:3000])
 PY
