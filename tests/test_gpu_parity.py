@@ -440,3 +440,36 @@ def test_two_diagonal_schedule_bit_exact(ctx, params, contra, short):
     r, rz = O.bpp(params.ptr, seqs[k], contra, short)
     assert_same(two[k].packed, r, "longest member")
     assert np.float32(logz2[k]).view(np.uint32) == np.float32(rz).view(np.uint32)
+
+
+@pytest.mark.parametrize("contra,short", [(False, False), (True, True)])
+def test_two_kernel_outside_sweep_bit_exact(params, contra, short):
+    """Large outside launches run the multibranch half of the pair probabilities as a kernel
+    of its own on a second stream, beside the other two roles.  Forced onto every launch of
+    a ragged batch (dual_min_cells = 0): same bits as the oracle, same bits as the one-kernel
+    form, and the per-kernel accounting (profile level 2) sees both kernels once per
+    diagonal."""
+    from rna_algos_amd.mccaskill_algo import Context
+    rng = np.random.default_rng(77 + int(contra))
+    lens = list(rng.integers(60, 260, 40)) + [1, 2, 5, 333]
+    seqs = [rng.integers(0, 4, int(n)).astype(np.uint8) for n in lens]
+    ctx = Context(params, device=0)
+    try:
+        ctx.set("dual_min_cells", 0)
+        ctx.set("profile", 2)
+        two, logz2 = ctx.bpp_batch(seqs, contra, short)
+        st = ctx.stats()
+        assert st["launches_outside_main"] == st["launches_outside_tail"] > 300
+        assert st["ms_outside_main"] > 0 and st["ms_outside_tail"] > 0
+        ctx.set("dual_outside", 0)
+        one, logz1 = ctx.bpp_batch(seqs, contra, short)
+        st = ctx.stats()
+        assert st["launches_outside_main"] == 0 and st["launches_outside_small"] > 300
+    finally:
+        ctx.close()
+    ref, ref_logz = O.bpp_batch(params.ptr, seqs, contra, short, n_threads=16)
+    for s, a, b, r in zip(seqs, one, two, ref):
+        assert np.array_equal(np.asarray(a.packed).view(np.uint32), np.asarray(b.packed).view(np.uint32))
+        assert_same(b.packed, r, f"n={len(s)}")
+    assert np.array_equal(np.asarray(logz2).view(np.uint32), np.asarray(ref_logz).view(np.uint32))
+    assert np.array_equal(np.asarray(logz1).view(np.uint32), np.asarray(ref_logz).view(np.uint32))
