@@ -146,6 +146,9 @@ def main():
     ap.add_argument("--workload", default="batch10k", choices=["batch10k", "n4096", "n1024"])
     ap.add_argument("--model", default="turner", choices=["turner", "contra"])
     ap.add_argument("--batch-count", type=int, default=10000)
+    ap.add_argument("--rehearse-shard", default="",
+                    help="W:R — single process, run the shard rank R of W ranks would get "
+                         "(rehearsal of the per-rank time of a multi-GPU run; value is per-shard)")
     ap.add_argument("--group-max-seqs", type=int, default=0)
     ap.add_argument("--group-max-nt", type=int, default=0)
     ap.add_argument("--group-ws-gb", type=int, default=0)
@@ -175,7 +178,11 @@ def main():
     seqs, label = build_workload(args.workload, args.batch_count)
     lens_all = np.array([len(s) for s in seqs], dtype=np.int64)
     costs = W.pair_cost(lens_all)
-    if len(seqs) >= world:
+    if args.rehearse_shard:
+        rw, rr = (int(x) for x in args.rehearse_shard.split(":"))
+        mine = shard_lpt(costs, rw)[rr]
+        label += f" [shard {rr} of {rw}]"
+    elif len(seqs) >= world:
         mine = shard_lpt(costs, world)[rank]
     else:  # fewer units than ranks (single-sequence workloads): replicas
         mine = np.arange(len(seqs))
