@@ -44,6 +44,11 @@ struct rnamc_ctx {
   uint64_t ws_floats = 0;
   SeqDesc* d_seqs = nullptr;
   uint64_t seqs_cap = 0;
+  // host-buffer entry: device staging of bases / result / log partition (grow-only)
+  uint8_t* st_bases = nullptr;
+  float* st_out = nullptr;
+  float* st_logz = nullptr;
+  uint64_t st_bases_cap = 0, st_out_cap = 0, st_logz_cap = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t aux_stream = nullptr;           // pair tail of large outside launches
   std::vector<hipEvent_t> ev_a, ev_b;         // per-diagonal completion, ring of 16
@@ -60,6 +65,7 @@ struct rnamc_ctx {
   int64_t dual_outside = 1;   // large outside launches: pair tail as its own kernel/stream
   uint64_t dual_min_cells = 256 * 1024;
   int64_t dual_max_diag = 1 << 30;  // ... while the diagonal has at most this many cells
+  bool inside_only = false;  // set by rnamc_fold_scores around its own batch call
   int64_t fuse_inside = 1;  // Turner: fold two diagonals per launch where launches are large
   int64_t debug_roles = 15;  // timing experiments only: bit0 folds, 1 pair block, 2 mb, 3 pair probs
   // bookkeeping of the last call
@@ -320,6 +326,9 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
       }
     }
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 1], st));
+    // (rnamc_fold_scores needs the sums_close key set only: no outside sweep; the output
+    // triangle then holds -1 / expf of stale log-probabilities and is not looked at)
+    if (!c->inside_only)
     // Outside sweep.  Launch d carries probs_multibranch and the pair tail of diagonal d and
     // the 2-loop half (pair head) of diagonal d-1: start one diagonal early.  Large launches
     // run the pair tail as its own kernel on a second stream beside the other two roles
@@ -555,6 +564,9 @@ void rnamc_ctx_destroy(rnamc_ctx* c) {
     for (hipEvent_t e : c->ev_b) (void)hipEventDestroy(e);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->st_bases) (void)hipFree(c->st_bases);
+    if (c->st_out) (void)hipFree(c->st_out);
+    if (c->st_logz) (void)hipFree(c->st_logz);
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->d_hp_init) (void)hipFree(c->d_hp_init);
     if (c->d_ws) (void)hipFree(c->d_ws);
@@ -635,34 +647,50 @@ int rnamc_bpp_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* bases, const u
     dout[s + 1] = dout[s] + rnamc_bpp_len(static_cast<uint32_t>(offsets[s + 1] - offsets[s]));
   }
   doff[n_seqs] = base_hi - base_lo;
-  uint8_t* d_bases = nullptr;
-  float* d_out = nullptr;
-  float* d_logz = nullptr;
+  // staging buffers live in the context and only grow (a caller that folds one record
+  // after another, like the reference's binaries, would otherwise pay a hipMalloc/hipFree
+  // triple per call)
   int rc = RNAMC_OK;
-  auto cleanup = [&]() {
-    if (d_bases) (void)hipFree(d_bases);
-    if (d_out) (void)hipFree(d_out);
-    if (d_logz) (void)hipFree(d_logz);
-  };
 #define HIPCHK_CLEAN(expr)                                                 \
   do {                                                                     \
     hipError_t _e = (expr);                                                \
     if (_e != hipSuccess) {                                                \
       set_last_error(std::string(#expr) + ": " + hipGetErrorString(_e));   \
-      cleanup();                                                           \
       return (_e == hipErrorOutOfMemory) ? RNAMC_ERR_OOM : RNAMC_ERR_HIP;  \
     }                                                                      \
   } while (0)
-  HIPCHK_CLEAN(hipMalloc(&d_bases, std::max<uint64_t>(base_hi - base_lo, 1)));
-  HIPCHK_CLEAN(hipMalloc(&d_out, std::max<uint64_t>(dout[n_seqs], 1) * sizeof(float)));
-  HIPCHK_CLEAN(hipMalloc(&d_logz, n_seqs * sizeof(float)));
+  auto grow = [&](void** p, uint64_t* cap, uint64_t need) -> hipError_t {
+    if (*cap >= need && *p) return hipSuccess;
+    if (*p) {
+      (void)hipStreamSynchronize(c->own_stream);
+      (void)hipFree(*p);
+      *p = nullptr;
+      *cap = 0;
+    }
+    const uint64_t want = std::max<uint64_t>(need + need / 4, 4096);
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess) {  // the headroom is optional
+      e = hipMalloc(p, std::max<uint64_t>(need, 1));
+      if (e == hipSuccess) *cap = std::max<uint64_t>(need, 1);
+      return e;
+    }
+    *cap = want;
+    return hipSuccess;
+  };
+  HIPCHK_CLEAN(grow(reinterpret_cast<void**>(&c->st_bases), &c->st_bases_cap, base_hi - base_lo));
+  HIPCHK_CLEAN(grow(reinterpret_cast<void**>(&c->st_out), &c->st_out_cap,
+                    dout[n_seqs] * sizeof(float)));
+  HIPCHK_CLEAN(grow(reinterpret_cast<void**>(&c->st_logz), &c->st_logz_cap,
+                    static_cast<uint64_t>(n_seqs) * sizeof(float)));
+  uint8_t* d_bases = c->st_bases;
+  float* d_out = c->st_out;
+  float* d_logz = c->st_logz;
   HIPCHK_CLEAN(hipMemcpyAsync(d_bases, bases + base_lo, base_hi - base_lo, hipMemcpyHostToDevice,
                               c->own_stream));
   rc = run_batch(c, n_seqs, d_bases, doff.data(), uses_contra_model != 0,
                  allows_short_hairpins != 0, d_out, dout.data(), d_logz, c->own_stream);
   if (rc) {
     (void)hipStreamSynchronize(c->own_stream);
-    cleanup();
     return rc;
   }
   for (uint32_t s = 0; s < n_seqs; s++) {
@@ -675,7 +703,11 @@ int rnamc_bpp_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* bases, const u
                                 hipMemcpyDeviceToHost, c->own_stream));
   HIPCHK_CLEAN(hipStreamSynchronize(c->own_stream));
 #undef HIPCHK_CLEAN
-  cleanup();
+  if (c->st_out_cap > (1ull << 30)) {  // a big one-off batch should not keep its result staged
+    (void)hipFree(c->st_out);
+    c->st_out = nullptr;
+    c->st_out_cap = 0;
+  }
   return RNAMC_OK;
 }
 
@@ -734,8 +766,10 @@ int rnamc_fold_scores(rnamc_ctx* c, const uint8_t* bases, uint32_t n, int uses_c
   const uint64_t offsets[2] = {0, n}, out_offsets[2] = {0, 0};
   const uint64_t tri_len = rnamc_bpp_len(n);
   std::vector<float> bpp(tri_len);
+  c->inside_only = true;
   int rc = rnamc_bpp_batch(c, 1, bases, offsets, uses_contra_model, allows_short_hairpins,
                            bpp.data(), out_offsets, nullptr);
+  c->inside_only = false;
   if (rc) return rc;
   DeviceGuard guard(c->device);
   if (!guard.ok) return RNAMC_ERR_NO_DEVICE;
