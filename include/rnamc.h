@@ -202,7 +202,8 @@ int rnamc_ctx_create(const rnamc_params* params, int device, uint64_t workspace_
                      rnamc_ctx** out);
 void rnamc_ctx_destroy(rnamc_ctx* ctx);
 /* Tuning knobs (all optional): name in {"group_max_seqs","group_max_nt","group_ws_bytes",
- * "block_threads","fuse_inside","order_inside","order_outside","profile"}; returns RNAMC_ERR_INVALID_ARG for unknown names. */
+ * "block_threads","fuse_inside","dual_outside","dual_min_cells","dual_max_diag",
+ * "order_inside","order_outside","profile"}; returns RNAMC_ERR_INVALID_ARG for unknown names. */
 int rnamc_ctx_set(rnamc_ctx* ctx, const char* name, int64_t value);
 
 /* mccaskill_algo over a batch (src/mccaskill_algo.rs:247-280 for each record, as

@@ -473,3 +473,32 @@ def test_two_kernel_outside_sweep_bit_exact(params, contra, short):
         assert_same(b.packed, r, f"n={len(s)}")
     assert np.array_equal(np.asarray(logz2).view(np.uint32), np.asarray(ref_logz).view(np.uint32))
     assert np.array_equal(np.asarray(logz1).view(np.uint32), np.asarray(ref_logz).view(np.uint32))
+
+
+def test_one_context_from_many_threads(ctx, params, trnas):
+    """The reference's binaries call mccaskill_algo from a thread pool (src/bin/
+    mccaskill_algo.rs:58-93).  Calls on one context serialise inside the library: results
+    from 8 threads are the ones a single thread gets."""
+    import threading
+    seqs = [s for _, s in trnas]
+    want = [O.bpp(params.ptr, s, k % 2 == 1, False) for k, s in enumerate(seqs)]
+    got = [None] * len(seqs)
+    errs = []
+
+    def work(k):
+        try:
+            for _ in range(3):
+                mats, logz = ctx.bpp_batch([seqs[k]], k % 2 == 1, False)
+                got[k] = (mats[0].packed.copy(), np.float32(logz[0]))
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(seqs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs
+    for (packed, lz), (ref, rz) in zip(got, want):
+        assert_same(packed, ref)
+        assert lz.view(np.uint32) == np.float32(rz).view(np.uint32)
