@@ -46,6 +46,14 @@ def pair_cost(n):
     return n * (n * n - 1.0) / 6.0
 
 
+def sweep_cost(n):
+    """Measured cost model of one sequence on an MI355X, seconds: the Theta(n^3) folds plus
+    the Theta(n^2 * 496) 2-loop blocks (fit to a 512-sequence group of n ~ 2000 and a
+    4000-sequence group of n = 256..964).  Used to balance shards."""
+    n = np.asarray(n, dtype=np.float64)
+    return 3.25e-12 * pair_cost(n) + 6.6e-10 * n * n
+
+
 def paired_fraction(seq):
     """f = (#canonical pairs with span >= 5) / (n^2/2), measured on the input."""
     s = np.asarray(seq, dtype=np.int64)

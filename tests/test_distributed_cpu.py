@@ -20,8 +20,8 @@ def _worker(rank, world, port, q):
     import bench
     from rna_algos_amd import workloads as W
     lens = W.batch_lengths(400)
-    costs = W.pair_cost(lens)
-    mine = bench.shard_lpt(costs, world)[rank]
+    costs = W.sweep_cost(lens)
+    mine = bench.shard_banded(costs, world)[rank]
     # what the ranks exchange: a barrier and the max of the local step time
     dist.barrier()
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)

@@ -134,6 +134,13 @@ def test_lpt_sharding_properties():
         assert sorted(allidx.tolist()) == list(range(1000))
         loads = np.array([costs[s].sum() for s in shards])
         assert loads.max() / loads.mean() < 1.01  # LPT balance on this distribution
+        bands = bench.shard_banded(costs, world)
+        assert sorted(np.concatenate(bands).tolist()) == list(range(1000))
+        loads = np.array([costs[s].sum() for s in bands])
+        assert loads.max() / loads.mean() < 1.03
+        # bands are contiguous in cost: rank r's cheapest unit is no cheaper than rank r+1's dearest
+        for a, b in zip(bands, bands[1:]):
+            assert costs[a].min() >= costs[b].max()
 
 
 def test_workload_generators(built):
