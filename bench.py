@@ -167,6 +167,8 @@ def main():
     ap.add_argument("--param-seed", type=int, default=1)
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-n4096", action="store_true",
+                    help="skip the single n=4096 sequence (second half of BASELINE.json's metric)")
     args = ap.parse_args()
 
     import torch
@@ -373,6 +375,26 @@ def main():
         }
         if args.workload != "batch10k":
             res["ms_per_seq"] = elapsed * 1e3 / steps
+        elif world == 1 and not args.no_n4096 and not args.rehearse_shard:
+            # the other half of the metric: ms per sequence at n = 4096 (BASELINE.json
+            # configs[2]: Turner), one warm-up + one timed call, device-resident
+            s4 = W.synthetic_seq(4096, 4096)
+            b4 = torch.from_numpy(s4).to(dev)
+            o4 = torch.empty(4096 * 4097 // 2, dtype=torch.float32, device=dev)
+            z4 = torch.empty(1, dtype=torch.float32, device=dev)
+            off4 = np.array([0, 4096], dtype=np.uint64)
+            oo4 = np.array([0, 4096 * 4097 // 2], dtype=np.uint64)
+            for k in range(2):
+                torch.cuda.synchronize()
+                t4 = time.perf_counter()
+                ctx.bpp_batch_device(1, b4.data_ptr(), off4, contra, False, o4.data_ptr(), oo4,
+                                     z4.data_ptr(), stream)
+                torch.cuda.synchronize()
+                t4 = time.perf_counter() - t4
+            res["ms_per_seq_n4096"] = t4 * 1e3
+            res["n4096_note"] = ("single n=4096 sequence, same tables: a lock-step group of one is "
+                                 "bound by the sequential fold chains the reference's summation "
+                                 "order dictates (2 x 8.4 M dependent steps), not by HBM")
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(params, my_seqs, contra, args.cpu_budget_s)
         print(json.dumps(res), flush=True)
