@@ -731,6 +731,7 @@ __device__ __forceinline__ void inside_sums_pair2(const DeviceBatch& b, const Se
 // so a k-step costs one dependent fold instead of three.  Same operations per chain
 // as inside_sums_cell, bit for bit.
 constexpr uint32_t kSplitCells = 21;
+constexpr int kUL = 32;  // fold steps fetched ahead in the latency forms
 template <bool CONTRA>
 __device__ __forceinline__ void inside_sums_split(const DeviceBatch& b, const Seq& q, uint32_t d,
                                                   uint32_t cell0, const LseTab* tab) {
@@ -763,17 +764,17 @@ __device__ __forceinline__ void inside_sums_split(const DeviceBatch& b, const Se
     const bool live = valid && chain < 2;
     const float* __restrict__ qa = q.m[M_QA];
     struct ABuf {
-      float xs[kU];
+      float xs[kUL];
     };
-    uint32_t t = pingpong<ABuf>(
-        1u, d / kU,
+    uint32_t t = pingpong<ABuf, kUL>(
+        1u, d / kUL,
         [&](ABuf& B, uint32_t t0) {
 #pragma unroll
-          for (int u = 0; u < kU; u++) B.xs[u] = ldu(qa + tri_off(n, t0 + u), i4);
+          for (int u = 0; u < kUL; u++) B.xs[u] = ldu(qa + tri_off(n, t0 + u), i4);
         },
         [&](const ABuf& B, uint32_t t0) {
 #pragma unroll
-          for (int u = 0; u < kU; u++) {
+          for (int u = 0; u < kUL; u++) {
             const float x = live ? B.xs[u] : kNegInf;
             zr = lse(zr, x + P + Q * static_cast<float>(d - t0 - u), tab);
           }
@@ -810,21 +811,23 @@ __device__ __forceinline__ void inside_sums_split(const DeviceBatch& b, const Se
     }
     acc = lse(acc, term, tab);
   };
+  // chunks of kUL steps: a lone wave per SIMD folds 8 steps in 0.7 us, less than one HBM
+  // round trip, so the operands are fetched 32 steps (2.8 us) ahead
   struct SBuf {
-    float ra[kU], rb[kU];
+    float ra[kUL], rb[kUL];
   };
-  uint32_t t = pingpong<SBuf>(
-      1u, d >= 1 ? (d - 1) / kU : 0u,
+  uint32_t t = pingpong<SBuf, kUL>(
+      1u, d >= 1 ? (d - 1) / kUL : 0u,
       [&](SBuf& B, uint32_t t0) {
 #pragma unroll
-        for (int u = 0; u < kU; u++) {
+        for (int u = 0; u < kUL; u++) {
           B.ra[u] = pa[tri_off(n, d - t0 - u) + t0 + u + ii];
           B.rb[u] = pb[tri_off(n, t0 + u - 1) + ii];
         }
       },
       [&](const SBuf& B, uint32_t t0) {
 #pragma unroll
-        for (int u = 0; u < kU; u++) step(B.ra[u], B.rb[u], t0 + u);
+        for (int u = 0; u < kUL; u++) step(B.ra[u], B.rb[u], t0 + u);
       });
   for (; t < d; t++) step(pa[tri_off(n, d - t) + t + ii], pb[tri_off(n, t - 1) + ii], t);
   // gather the three chains of a cell onto its chain-0 lane
@@ -1192,7 +1195,8 @@ __device__ __forceinline__ void outside_pair_tail(const DeviceBatch& b, const Se
   // lane fetches whole lines of its own columns (64-byte pieces read 11 % slower) into ONE
   // buffer per stream (64 VGPRs).  Double-buffering them (112 VGPRs, 3 waves per SIMD) was
   // 12 % slower over the whole outside sweep: the other waves of the SIMD hide the fetch
-  // latency better than a deeper pipeline that starves every role of registers.
+  // latency better than a deeper pipeline that starves every role of registers (and on a
+  // single long sequence, where this chain is the critical path, it gained nothing).
   const uint32_t nch = (imax_wave + 15u) / 16u;
   if (nch) {
     float4 xl[8], yl[8];
