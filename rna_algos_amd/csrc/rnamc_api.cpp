@@ -585,7 +585,8 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     c->group_max_nt = value;
   } else if (k == "group_ws_bytes" && value >= 4) {
     c->group_ws_bytes = value;
-  } else if (k == "block_threads" && value >= 64 && value <= 1024 && value % 64 == 0) {
+  } else if (k == "block_threads" && value >= 64 && value <= 256 && value % 64 == 0) {
+    // (the sweep kernels are compiled with __launch_bounds__(256))
     c->block_threads = value;
   } else if (k == "profile") {
     c->profile = value;
