@@ -33,6 +33,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <type_traits>
 
 #include "rnamc_device.h"
 #include "rnamc_scoring.h"

@@ -342,8 +342,13 @@ __device__ __forceinline__ float probe_fold(const DeviceBatch& b, const Seq& q, 
   const bool lane_l_ok = act && (!OUTSIDE || j + 2 <= n);
   const char* gbase = reinterpret_cast<const char*>(&L.g[0][0]);
 
-  // one chunk: probes (a, b0 .. b0+kPU-1)
-  auto do_chunk = [&](const PBuf& B, uint32_t a, uint32_t b0) {
+  // one chunk: probes (a, b0 .. b0+kPU-1).  KIND (compile time) keeps the per-probe
+  // conditions out of the common case: 0 = first chunk of a row (the small loops and the
+  // loop classes of b <= 3 live here), 1 = a later, full chunk (every probe is a generic
+  // interior loop or the row's bulge / 1xn tail class), 2 = a later, partial chunk,
+  // 3 = decide at run time.
+  auto do_chunk = [&](const PBuf& B, uint32_t a, uint32_t b0, auto kind) {
+    constexpr int KIND = decltype(kind)::value;
     // row constants: 4-bit slice of the a-side window -> byte offset of r in a float2 row
     const uint32_t rs = OUTSIDE ? static_cast<uint32_t>(wa64 >> (2u * (30u - a))) & 15u
                                 : static_cast<uint32_t>(wa64 >> (2u * a)) & 15u;
@@ -367,9 +372,9 @@ __device__ __forceinline__ float probe_fold(const DeviceBatch& b, const Seq& q, 
       const uint32_t bb = b0 + u;
       const uint32_t ts = static_cast<uint32_t>(wcur) & 15u;
       wcur >>= 2;
-      if (bb < rowlen) {
+      if (KIND == 1 || bb < rowlen) {
         float y;
-        if (u <= 2 && b0 == 0 && a <= 2) {
+        if ((KIND == 0 || (KIND == 3 && b0 == 0)) && u <= 2 && a <= 2) {
           // the nine small loops: general path
           if (!OUTSIDE) {
             c.a1 = static_cast<int>(ts >> 2);
@@ -384,7 +389,7 @@ __device__ __forceinline__ float probe_fold(const DeviceBatch& b, const Seq& q, 
         } else {
           uint32_t cls = rcls;
           float ftm = rtm;
-          if (u <= 3 && b0 == 0 && !CONTRA) {
+          if ((KIND == 0 || (KIND == 3 && b0 == 0)) && u <= 3 && !CONTRA) {
             cls = loop_class(a, bb);
             ftm = (cls == 3u) ? 0.f : (cls == 0u ? fx.tm0 : (cls == 1u ? fx.tm1 : fx.tm2));
           }
@@ -412,7 +417,21 @@ __device__ __forceinline__ float probe_fold(const DeviceBatch& b, const Seq& q, 
     }
   };
 
-  // two-stage pipeline over the chunk sequence (rows a ascending, chunks b0 ascending)
+  // two-stage pipeline over the chunk sequence (rows a ascending, chunks b0 ascending).
+  // Inside, the next chunk is fetched unconditionally (past the end: the last row's first
+  // probe again), so the number of loads in flight at every wait is static; outside (two
+  // operands per probe) the conditional form measured faster.
+  auto fold_chunk = [&](const PBuf& B, uint32_t a, uint32_t b0) {
+    if (OUTSIDE) {  // one body with run-time conditions (3): measured faster there
+      do_chunk(B, a, b0, std::integral_constant<int, 3>{});
+    } else if (b0 == 0) {
+      do_chunk(B, a, b0, std::integral_constant<int, 0>{});
+    } else if (b0 + kPU <= lim - a + 1) {
+      do_chunk(B, a, b0, std::integral_constant<int, 1>{});
+    } else {
+      do_chunk(B, a, b0, std::integral_constant<int, 2>{});
+    }
+  };
   PBuf A, B;
   uint32_t a = 0, b0 = 0;    // chunk being folded
   uint32_t fa = 0, fb = 0;   // next chunk to fetch
@@ -420,15 +439,15 @@ __device__ __forceinline__ float probe_fold(const DeviceBatch& b, const Seq& q, 
   chunk_next(fa, fb);
   for (;;) {
     bool more = fa <= lim;
-    if (more) fetch(B, fa, fb);
-    do_chunk(A, a, b0);
+    if (!OUTSIDE || more) fetch(B, more ? fa : lim, more ? fb : 0u);
+    fold_chunk(A, a, b0);
     if (!more) break;
     a = fa;
     b0 = fb;
     chunk_next(fa, fb);
     more = fa <= lim;
-    if (more) fetch(A, fa, fb);
-    do_chunk(B, a, b0);
+    if (!OUTSIDE || more) fetch(A, more ? fa : lim, more ? fb : 0u);
+    fold_chunk(B, a, b0);
     if (!more) break;
     a = fa;
     b0 = fb;
