@@ -12,21 +12,26 @@
 // Mapping (MI355X-first, not a translation of the Rust loops):
 //  * the sweep is by anti-diagonal d = j - i; all cells of one diagonal of ALL
 //    sequences of a group are independent and are processed by one launch;
-//  * one lane owns one cell (i, i+d); lanes of a wave own consecutive i, so with
-//    the packed layouts of rnamc_internal.h the operands of the inside folds and of
-//    probs_multibranch are contiguous 256-B wave accesses, and the pair-probability
-//    tail streams lane-private columns in 64-byte pieces (it uses every byte it fetches);
-//  * the reduction index k is walked sequentially per lane (order is part of
-//    the result); parallelism comes from cells x sequences x independent folds,
-//    not from k.  Operands of the next chunk of k-steps are fetched into a second
-//    register buffer while the current chunk is folded (loads do not depend on the chain);
+//  * one lane owns one cell (i, i+d) — two cells (i, i+d), (i, i+d+1) in the large inside
+//    launches, which fold both off one stream of the shared row operands; lanes of a wave
+//    own consecutive i, so with the packed layouts of rnamc_internal.h the operands of the
+//    inside folds and of probs_multibranch are contiguous 256-B wave accesses, and the
+//    pair-probability tail streams lane-private columns in whole 128-byte lines;
+//  * the reduction index k is walked sequentially per lane (order is part of the result);
+//    parallelism comes from cells x sequences x independent folds, not from k.  Operands
+//    of the next chunk of k-steps are fetched while the current chunk is folded;
 //  * the 8-piece cubic of logsumexp is evaluated branch-free: a 42-cell LDS table
 //    and one compare give the piece, one ds_read_b128 its 4 coefficients;
 //  * hot loops carry no exec-mask branches: loads are unconditional (matrices are
-//    padded), lane validity is applied to the loaded values;
+//    padded), lane validity is applied to the loaded values; wave-uniform trip counts are
+//    passed through readfirstlane so that loop control stays scalar;
+//  * registers are spent on occupancy rather than on deep software pipelines (the sweeps
+//    are bound by the loads the resident waves keep in flight): the pair tail holds ONE
+//    line per stream, and runs as a kernel of its own beside the other outside roles;
 //  * each launch carries independent roles in disjoint blocks: inside = {folds of
-//    diagonal d, closing-pair block of diagonal d+1}, outside = {probs_multibranch of d,
-//    multibranch half of the pair probabilities of d, 2-loop half of d-1};
+//    diagonals d, d+1; early part of the closing-pair blocks of d+2, d+3}, outside =
+//    {probs_multibranch of d, 2-loop half of the pair probabilities of d-1} beside
+//    {multibranch half of the pair probabilities of d};
 //  * block ids walk over sequences first so that the 8 XCDs get equal mixes of
 //    light and heavy blocks; heavy blocks are issued first.
 #include <hip/hip_runtime.h>
