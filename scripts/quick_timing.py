@@ -9,8 +9,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-import oracle_lib as O  # noqa: E402
+from rna_algos_amd import workloads as WL0  # noqa: E402
 from rna_algos_amd.utils import FoldScoreSets  # noqa: E402
 from rna_algos_amd.mccaskill_algo import Context  # noqa: E402
 
@@ -80,11 +79,11 @@ def main():
     what = sys.argv[1:] or ["n1024", "n4096", "batch256"]
     for w in what:
         if w == "n1024":
-            run(ctx, [O.splitmix_seq(1024, 1024)], True, label="n1024")
-            run(ctx, [O.splitmix_seq(1024, 1024)], False, label="n1024")
+            run(ctx, [WL0.synthetic_seq(1024, 1024)], True, label="n1024")
+            run(ctx, [WL0.synthetic_seq(1024, 1024)], False, label="n1024")
         elif w == "n4096":
-            run(ctx, [O.splitmix_seq(4096, 4096)], False, label="n4096")
-            run(ctx, [O.splitmix_seq(4096, 4096)], True, reps=1, label="n4096")
+            run(ctx, [WL0.synthetic_seq(4096, 4096)], False, label="n4096")
+            run(ctx, [WL0.synthetic_seq(4096, 4096)], True, reps=1, label="n4096")
         elif w.startswith("top"):
             # the `cnt` longest sequences of the 10k batch: what one lock-step group really holds
             cnt = int(w[3:])

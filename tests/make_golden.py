@@ -1,7 +1,7 @@
 """Generates tests/golden/*.json|npz from the CPU oracle with the seeded synthetic
 tables ("self-golden, synthetic tables": the reference itself cannot run here and
 holds no golden vectors for this path — SURVEY.md §8c).  Usage:
-    python scripts/make_golden.py [small|n1024|n4096_turner|n4096_contra]
+    python tests/make_golden.py [small|n1024|n4096_turner|n4096_contra]
 """
 import hashlib
 import json

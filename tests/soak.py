@@ -1,6 +1,6 @@
 """Randomised soak of the HIP path against the CPU oracle: ragged batches, all three model
-variants, random scheduling knobs.  Not part of the pytest suites (minutes of oracle time);
-run on the GPU box:  python scripts/soak.py [rounds] [seed]"""
+variants, random scheduling knobs.  Test infrastructure, not collected by pytest (minutes
+of oracle time); run on the GPU box:  python tests/soak.py [rounds] [seed]"""
 import os
 import sys
 
@@ -8,7 +8,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import oracle_lib as O  # noqa: E402
 from rna_algos_amd.utils import FoldScoreSets  # noqa: E402
 from rna_algos_amd.mccaskill_algo import Context  # noqa: E402

@@ -354,7 +354,7 @@ def test_other_tables_and_low_complexity(built, seed):
 
 def test_bench_batch_members_golden(ctx, params):
     """Sequences 0, 1, 3 of the bench's own 10k batch (lengths 1653, 1024, 531), both
-    models, against the oracle's committed checksums (scripts/make_golden.py batch)."""
+    models, against the oracle's committed checksums (tests/make_golden.py batch)."""
     from rna_algos_amd import workloads as W
     g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "checksums_batch.json")))["cases"]
     lens = W.batch_lengths(8)
