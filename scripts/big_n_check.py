@@ -1,4 +1,5 @@
-"""One-off sanity check at lengths no oracle run can pin (n = 8192, 12001): key set,\nrange and row sums of the base-pairing probabilities.  Run on the GPU box."""
+"""One-off sanity check at lengths no oracle run can pin (n = 8192, 12001): key set,
+range and row sums of the base-pairing probabilities.  Run on the GPU box."""
 import sys, time, numpy as np
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
