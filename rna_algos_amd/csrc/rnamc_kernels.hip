@@ -1037,16 +1037,24 @@ __device__ __forceinline__ void outside_mb_cell(const DeviceBatch& b, const Seq&
   };
   auto issue = [&](DOps& B, const DAux& A) {
     const uint32_t t0 = A.t0;
-    uint32_t bits = 0;
+    uint32_t bits = 0, off[kU];
 #pragma unroll
     for (int u = 0; u < kU; u++) {
       bool has;
-      const uint32_t off = locate(A.win, u, t0 + u, A.base[u], has);
-      B.xs[u] = ldu(w + tri_off(n, d + t0 + u), off);
-      B.rs[u] = ldu(q1d + tri_off(n, t0 + u - 2) + d + 1, i4);
+      off[u] = locate(A.win, u, t0 + u, A.base[u], has);
       bits |= (has ? 1u : 0u) << u;
     }
     B.bits = bits;
+    // lanes whose row ended before this chunk (the upper lanes of the wave: the walk runs
+    // to the first lane's end) issue no loads; their buffers keep finite values and their
+    // terms are masked by `bits`
+    if (t0 <= cnt) {
+#pragma unroll
+      for (int u = 0; u < kU; u++) {
+        B.xs[u] = ldu(w + tri_off(n, d + t0 + u), off[u]);
+        B.rs[u] = ldu(q1d + tri_off(n, t0 + u - 2) + d + 1, i4);
+      }
+    }
   };
   auto fold = [&](const DOps& B, uint32_t t0) {
 #pragma unroll
@@ -1082,6 +1090,8 @@ __device__ __forceinline__ void outside_mb_cell(const DeviceBatch& b, const Seq&
     const uint32_t t_last = 2u + (nch - 1u) * kU;
     DAux xa, xb;
     DOps oa, ob;
+#pragma unroll
+    for (int u = 0; u < kU; u++) oa.xs[u] = oa.rs[u] = ob.xs[u] = ob.rs[u] = 0.f;
     load_aux(xa, t);
     load_aux(xb, min(t + kU, t_last));
     issue(oa, xa);
@@ -1216,12 +1226,16 @@ __device__ __forceinline__ void outside_pair_tail(const DeviceBatch& b, const Se
       }
     };
     for (uint32_t c = 0, k = 0; c < nch; c++, k += 16) {
-      if ((c & 1u) == 0u) {
+      // the streams are lane-private, so a lane past its own walk (the wave runs to its
+      // longest lane's end) issues no loads: nothing is fetched for steps that fold nothing
+      if (k < iend) {
+        if ((c & 1u) == 0u) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) xl[u] = xcol[k / 4 + u];
+          for (int u = 0; u < 8; u++) xl[u] = xcol[k / 4 + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) yl[u] = yycol[k / 2 + u];
       }
-#pragma unroll
-      for (int u = 0; u < 8; u++) yl[u] = yycol[k / 2 + u];
       if ((c & 1u) == 0u) fold16l(&xl[0], yl, k); else fold16l(&xl[4], yl, k);
     }
   }
