@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--param-seed", type=int, default=1)
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="skip the extra pass that times every outside kernel with HIP events")
     ap.add_argument("--no-n4096", action="store_true",
                     help="skip the single n=4096 sequence (second half of BASELINE.json's metric)")
     args = ap.parse_args()
@@ -262,7 +264,7 @@ def main():
     # outside-sweep kernel (on the stream it is launched on): per-kernel durations for the
     # roofline of the dominant kernel.  Those event records cost ~2 %, so the timed steps
     # above run without them.
-    if rank == 0:
+    if rank == 0 and not args.no_kernel_timing:
         ctx.set("profile", 2)
         step()
         st = ctx.stats()

@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_traffic_$TAG
 rm -rf $OUT && mkdir -p $OUT
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d $OUT/$C -- python3 $R/bench.py "$@" --no-cpu-baseline --steps 1 --warmup 0 > $OUT/bench_$C.json 2> $OUT/$C.err || { tail -5 $OUT/$C.err; exit 1; }
+  rocprofv3 --pmc $C --output-format csv -d $OUT/$C -- python3 $R/bench.py "$@" --no-cpu-baseline --no-kernel-timing --no-n4096 --steps 1 --warmup 0 > $OUT/bench_$C.json 2> $OUT/$C.err || { tail -5 $OUT/$C.err; exit 1; }
 done
 python3 - <<PY
 import csv, glob, json, collections
