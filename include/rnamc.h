@@ -189,6 +189,15 @@ int rnamc_params_load(const char* path, rnamc_params* out);
 /* Enumerate the f32 array fields of rnamc_params (for host-language mirrors):
  * returns RNAMC_ERR_INVALID_ARG when idx is past the end. */
 int rnamc_params_field(uint32_t idx, const char** name, uint64_t* byte_offset, uint64_t* count);
+/* The non-float members, for host languages that do not mirror the struct:
+ * HAIRPIN_SCORES_SPECIAL (src/utils.rs:198-205): n entries, sequence x as len[x] base codes
+ * at seqs[x * RNAMC_MAX_SPECIAL_HAIRPIN_LEN ...]; and the three hairpin length constants
+ * (src/utils.rs:174-183). */
+int rnamc_params_set_special_hairpins(rnamc_params* p, uint32_t n, const uint8_t* seqs,
+                                      const uint8_t* lens, const float* scores);
+int rnamc_params_set_hairpin_limits(rnamc_params* p, uint32_t min_hairpin_len,
+                                    uint32_t max_hairpin_len_extrapolation,
+                                    uint32_t min_hairpin_len_extrapolation);
 
 /* ------------------------------------------------------------------------- */
 /* Device context: owns the uploaded tables, a workspace and streams on ONE

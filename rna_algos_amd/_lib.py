@@ -21,6 +21,7 @@ SYMBOLS = [
     "rnamc_fold_score_sets_new", "rnamc_fold_score_sets_accumulate",
     "rnamc_fold_score_sets_transfer", "rnamc_params_new", "rnamc_params_synthetic",
     "rnamc_params_save", "rnamc_params_load", "rnamc_params_field",
+    "rnamc_params_set_special_hairpins", "rnamc_params_set_hairpin_limits",
     "rnamc_ctx_create", "rnamc_ctx_destroy", "rnamc_ctx_set",
     "rnamc_bpp_batch", "rnamc_bpp_batch_device", "rnamc_ctx_last_stats",
     "rnamc_debug_fetch", "rnamc_fold_scores", "rnamc_centroid_fold",
@@ -81,6 +82,8 @@ def lib():
     L.rnamc_params_save.argtypes = [vp, C.c_char_p]
     L.rnamc_params_load.argtypes = [C.c_char_p, vp]
     L.rnamc_params_field.argtypes = [C.c_uint32, C.POINTER(C.c_char_p), u64p, u64p]
+    L.rnamc_params_set_special_hairpins.argtypes = [vp, C.c_uint32, vp, vp, vp]
+    L.rnamc_params_set_hairpin_limits.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
     L.rnamc_ctx_create.argtypes = [vp, C.c_int, C.c_uint64, C.POINTER(vp)]
     L.rnamc_ctx_destroy.argtypes = [vp]
     L.rnamc_ctx_destroy.restype = None

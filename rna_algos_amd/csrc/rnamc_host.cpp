@@ -374,6 +374,41 @@ int rnamc_params_load(const char* path, rnamc_params* out) {
   return st;
 }
 
+int rnamc_params_set_special_hairpins(rnamc_params* p, uint32_t n, const uint8_t* seqs,
+                                      const uint8_t* lens, const float* scores) {
+  if (!p || n > RNAMC_MAX_SPECIAL_HAIRPINS || (n && (!seqs || !lens || !scores)))
+    return RNAMC_ERR_INVALID_ARG;
+  for (uint32_t x = 0; x < n; x++) {
+    if (lens[x] == 0 || lens[x] > RNAMC_MAX_SPECIAL_HAIRPIN_LEN) return RNAMC_ERR_INVALID_ARG;
+    for (uint32_t y = 0; y < lens[x]; y++)
+      if (seqs[x * RNAMC_MAX_SPECIAL_HAIRPIN_LEN + y] > 3) return RNAMC_ERR_INVALID_BASE;
+  }
+  rnamc_turner_scores& t = p->turner;
+  std::memset(t.special_hairpin_seqs, 0, sizeof(t.special_hairpin_seqs));
+  std::memset(t.special_hairpin_lens, 0, sizeof(t.special_hairpin_lens));
+  for (uint32_t x = 0; x < RNAMC_MAX_SPECIAL_HAIRPINS; x++) t.special_hairpin_scores[x] = 0.f;
+  for (uint32_t x = 0; x < n; x++) {
+    std::memcpy(t.special_hairpin_seqs[x], seqs + x * RNAMC_MAX_SPECIAL_HAIRPIN_LEN, lens[x]);
+    t.special_hairpin_lens[x] = lens[x];
+    t.special_hairpin_scores[x] = scores[x];
+  }
+  t.num_special_hairpins = n;
+  return RNAMC_OK;
+}
+
+int rnamc_params_set_hairpin_limits(rnamc_params* p, uint32_t min_hairpin_len,
+                                    uint32_t max_hairpin_len_extrapolation,
+                                    uint32_t min_hairpin_len_extrapolation) {
+  if (!p || min_hairpin_len_extrapolation < 2 ||
+      max_hairpin_len_extrapolation > RNAMC_MAX_LOOP_LEN ||
+      min_hairpin_len_extrapolation - 1 > RNAMC_MAX_LOOP_LEN)
+    return RNAMC_ERR_INVALID_ARG;
+  p->turner.min_hairpin_len = min_hairpin_len;
+  p->turner.max_hairpin_len_extrapolation = max_hairpin_len_extrapolation;
+  p->turner.min_hairpin_len_extrapolation = min_hairpin_len_extrapolation;
+  return RNAMC_OK;
+}
+
 int rnamc_params_field(uint32_t idx, const char** name, uint64_t* byte_offset, uint64_t* count) {
   if (idx >= sizeof(kFields) / sizeof(kFields[0])) return RNAMC_ERR_INVALID_ARG;
   if (name) *name = kFields[idx].name;

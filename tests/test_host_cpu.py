@@ -188,3 +188,33 @@ def test_cli_text_formatting(built):
     packed[bpp_index(n, 0, 5)] = np.float32(0.1)
     assert probs2str(BppMatrix(n, packed)) == "0,5,0.1 1,6,0.25 "
     assert HEADER.startswith("# Format = >{RNA sequence id}")
+
+
+def test_params_setters_for_foreign_hosts(built):
+    """rnamc_params_set_special_hairpins / _set_hairpin_limits: what a host language that
+    does not mirror the struct (the Rust shim) uses for the non-float members."""
+    import ctypes as C
+    from rna_algos_amd import _lib
+    from rna_algos_amd.utils import FoldScoreSets
+    L = _lib.lib()
+    P = FoldScoreSets.synthetic(3)
+    seqs = np.zeros((2, 16), dtype=np.uint8)
+    seqs[0, :6] = [1, 0, 0, 0, 0, 2]
+    seqs[1, :5] = [2, 3, 3, 3, 1]
+    lens = np.array([6, 5], dtype=np.uint8)
+    scores = np.array([1.5, -0.25], dtype=np.float32)
+    assert L.rnamc_params_set_special_hairpins(P.ptr, 2, seqs.ctypes.data, lens.ctypes.data,
+                                               scores.ctypes.data) == 0
+    assert L.rnamc_params_set_hairpin_limits(P.ptr, 3, 9, 10) == 0
+    # the oracle reads the same block: the planted hairpin's score is picked up
+    seq = np.array([1, 0, 0, 0, 0, 2], dtype=np.uint8)
+    hp, _, _, _ = O.fold_scores(P.ptr, seq, 0, 0)
+    assert hp[len(seq) * (len(seq) + 1) // 2 - 1] == np.float32(1.5)
+    # rejected inputs
+    bad = lens.copy()
+    bad[0] = 17
+    assert L.rnamc_params_set_special_hairpins(P.ptr, 2, seqs.ctypes.data, bad.ctypes.data,
+                                               scores.ctypes.data) != 0
+    assert L.rnamc_params_set_special_hairpins(P.ptr, 65, seqs.ctypes.data, lens.ctypes.data,
+                                               scores.ctypes.data) != 0
+    assert L.rnamc_params_set_hairpin_limits(P.ptr, 3, 31, 10) != 0
