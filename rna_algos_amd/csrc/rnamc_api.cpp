@@ -179,11 +179,8 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
       const uint64_t ccnt_words = (static_cast<uint64_t>(n) + 63) & ~63ull;
       const uint64_t c64_words =
           ((static_cast<uint64_t>(n) + 63) / 64 * (static_cast<uint64_t>(n) + 64) + 63) & ~63ull;
-      // CONTRAfold: row lists of canonical partners (rowoff u32[n+1], rk u16 / rrank u16 per cell)
-      const uint64_t rowoff_words = contra ? ((static_cast<uint64_t>(n) + 1 + 63) & ~63ull) : 0;
-      const uint64_t rk_words = contra ? cidx_words : 0;
-      const uint64_t need = tri_pad_of(n) * M_COUNT + pk_words + cidx_words + ccnt_words +
-                            c64_words + rowoff_words + 2 * rk_words;
+      const uint64_t need =
+          tri_pad_of(n) * M_COUNT + pk_words + cidx_words + ccnt_words + c64_words;
       // a launch should carry enough cells to fill the chip: short sequences go into
       // larger groups (bounded by nucleotides, sequences and workspace bytes)
       if (cnt > 0 && (cnt >= static_cast<uint32_t>(c->group_max_seqs) ||
@@ -207,9 +204,6 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
       sd.cidx_off = sd.pk_off + pk_words;
       sd.ccnt_off = sd.cidx_off + cidx_words;
       sd.c64_off = sd.ccnt_off + ccnt_words;
-      sd.rowoff_off = sd.c64_off + c64_words;
-      sd.rk_off = sd.rowoff_off + rowoff_words;
-      sd.rrank_off = sd.rk_off + rk_words;
       c->descs.push_back(sd);
       cur += need;
       cur_nt += n;
@@ -273,7 +267,7 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
       return lo;
     };
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 0], st));
-    launch_init(b, contra, nseq, gmax, st);
+    launch_init(b, nseq, gmax, st);
     c->stats.launches_other++;
     // Inside sweep.  Dependencies: the closing-pair block of diagonal D is a left fold whose
     // early part (hairpin, 2-loops) needs sums_close of diagonals <= D-2 and whose last term
@@ -330,10 +324,6 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
         if (pair_next) pairs_done = heads_done = d + 1;
         d += 1;
       }
-    }
-    if (contra) {
-      launch_fill_w(b, nseq, gmax, st);
-      c->stats.launches_other++;
     }
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 1], st));
     // (rnamc_fold_scores needs the sums_close key set only: no outside sweep; the output

@@ -24,9 +24,7 @@ struct DeviceBatch {
   int order_inside, order_outside;  // order in which a launch's role blocks are dispatched
 };
 
-void launch_init(const DeviceBatch& b, bool contra, uint32_t nseq, uint32_t max_n, hipStream_t st);
-// CONTRAfold: W slot back to -inf between the passes (it holds row-list values inside)
-void launch_fill_w(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st);
+void launch_init(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st);
 // folds of diagonal d (do_sums) and closing-pair block of diagonal d+1 (do_pair)
 void launch_inside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
                    uint32_t block, bool do_sums, bool do_pair, hipStream_t st);

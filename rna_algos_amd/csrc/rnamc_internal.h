@@ -49,10 +49,6 @@ struct SeqDesc {
   uint64_t ccnt_off;  // float offset of the u32 list lengths (one per diagonal)
   uint64_t c64_off;   // float offset of the u32 table: canonical cells before position 64*w
                       // of diagonal D at [w * (n + 64) + D]
-  // CONTRAfold only (0 otherwise): per-row lists of canonical partners
-  uint64_t rowoff_off;  // u32[n+1]: start of row i's list (rows padded to 8 entries)
-  uint64_t rk_off;      // u16 per entry: partner k, ascending; 0xFFFF in the padding
-  uint64_t rrank_off;   // u16 per cell (diag-major): index of (i,k) in row i's list
 };
 
 }  // namespace rnamc

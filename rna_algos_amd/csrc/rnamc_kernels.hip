@@ -239,13 +239,6 @@ struct Seq {
   uint32_t* ccnt;
   // c64[w * (n + 64) + D]: canonical cells of diagonal D at positions < 64 w (0 for D >= n)
   uint32_t* c64;
-  // CONTRAfold: per-row lists of the canonical partners k of i, ascending (rows padded to 8
-  // entries with k = 0xFFFF); rowoff[i] = start of row i; rrank[cell] = index of the cell
-  // in its row's list.  The sums_accessible values of the list live in the W slot during
-  // the inside pass (entries of non-members stay -inf).
-  uint32_t* rowoff;
-  uint16_t* rk;
-  uint16_t* rrank;
 };
 
 __device__ __forceinline__ Seq load_seq(const DeviceBatch& b, uint32_t which) {
@@ -261,9 +254,6 @@ __device__ __forceinline__ Seq load_seq(const DeviceBatch& b, uint32_t which) {
   q.cidx = reinterpret_cast<uint16_t*>(b.workspace + sd.cidx_off);
   q.ccnt = reinterpret_cast<uint32_t*>(b.workspace + sd.ccnt_off);
   q.c64 = reinterpret_cast<uint32_t*>(b.workspace + sd.c64_off);
-  q.rowoff = reinterpret_cast<uint32_t*>(b.workspace + sd.rowoff_off);
-  q.rk = reinterpret_cast<uint16_t*>(b.workspace + sd.rk_off);
-  q.rrank = reinterpret_cast<uint16_t*>(b.workspace + sd.rrank_off);
   return q;
 }
 
@@ -382,75 +372,6 @@ __global__ void __launch_bounds__(64) k_compact(DeviceBatch b) {
     for (uint32_t x = lane; x < nb64 * 64u; x += 64) q.c64[(x >> 6) * stride + n + (x & 63u)] = 0u;
 }
 
-// CONTRAfold row lists, step 1: canonical partners k > i of every row i (count, padded to
-// a multiple of 8, left in rowoff[i+1]).  One wave per (sequence, row).
-__global__ void __launch_bounds__(64) k_rowcount(DeviceBatch b) {
-  const Seq q = load_seq(b, blockIdx.y);
-  const uint32_t n = q.n, i = blockIdx.x, lane = threadIdx.x;
-  if (i >= n) return;
-  const uint8_t* s = q.s;
-  const int a = s[i];
-  uint32_t cnt = 0;
-  for (uint32_t k0 = i + 1; k0 < n; k0 += 64) {
-    const uint32_t k = k0 + lane;
-    cnt += static_cast<uint32_t>(__popcll(__ballot(k < n && canonical(a, s[k]))));
-  }
-  if (lane == 0) q.rowoff[i + 1] = (cnt + 7u) & ~7u;
-}
-
-// step 2: exclusive prefix over the rows.  One wave per sequence.
-__global__ void __launch_bounds__(64) k_rowscan(DeviceBatch b) {
-  const Seq q = load_seq(b, blockIdx.x);
-  const uint32_t n = q.n, lane = threadIdx.x;
-  uint32_t carry = 0;
-  if (lane == 0) q.rowoff[0] = 0;
-  for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-    const uint32_t i = i0 + lane;
-    uint32_t v = (i < n) ? q.rowoff[i + 1] : 0u;
-#pragma unroll
-    for (int sh = 1; sh < 64; sh <<= 1) {
-      const uint32_t up = static_cast<uint32_t>(__shfl_up(static_cast<int>(v), sh));
-      if (lane >= static_cast<uint32_t>(sh)) v += up;
-    }
-    if (i < n) q.rowoff[i + 1] = carry + v;
-    carry += static_cast<uint32_t>(__shfl(static_cast<int>(v), 63));
-  }
-}
-
-// step 3: the lists (partner k) and, per cell, its index in its row's list.
-__global__ void __launch_bounds__(64) k_rowfill(DeviceBatch b) {
-  const Seq q = load_seq(b, blockIdx.y);
-  const uint32_t n = q.n, i = blockIdx.x, lane = threadIdx.x;
-  if (i >= n) return;
-  const uint8_t* s = q.s;
-  const int a = s[i];
-  const uint32_t base = q.rowoff[i], end = q.rowoff[i + 1];
-  uint32_t cnt = 0;
-  for (uint32_t k0 = i + 1; k0 < n; k0 += 64) {
-    const uint32_t k = k0 + lane;
-    const bool c = k < n && canonical(a, s[k]);
-    const unsigned long long m = __ballot(c);
-    if (c) {
-      const uint32_t r = cnt + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
-      q.rk[base + r] = static_cast<uint16_t>(k);
-      q.rrank[tri_off(n, k - i) + i] = static_cast<uint16_t>(r);
-    }
-    cnt += static_cast<uint32_t>(__popcll(m));
-  }
-  for (uint32_t r = base + cnt + lane; r < end; r += 64) q.rk[r] = 0xFFFFu;
-}
-
-// the W slot doubles as the row lists' sums_accessible during the CONTRAfold inside pass:
-// back to -inf before the outside pass uses it
-__global__ void k_fill_w(DeviceBatch b) {
-  const SeqDesc sd = b.seqs[blockIdx.y];
-  float* w = b.workspace + sd.ws_off + static_cast<size_t>(M_W) * sd.tri_pad;
-  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
-  for (size_t x = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; x < sd.tri_pad;
-       x += stride)
-    w[x] = kNegInf;
-}
-
 // lane -> listed cell of diagonal d; returns false for lanes past the list
 __device__ __forceinline__ bool listed_cell(const Seq& q, uint32_t d, uint32_t t, uint32_t cnt,
                                             uint32_t& i) {
@@ -509,7 +430,6 @@ __device__ __forceinline__ void inside_pair_cell(const DeviceBatch& b, const Seq
     q.m[M_MBC][o] = mbc;
     q.m[M_QB][o] = sum;
     q.m[M_QA][o] = sum + acc;
-    if (CONTRA) q.m[M_W][q.rowoff[i] + q.rrank[o]] = sum + acc;  // row list, see inside_zr_pair2
   }
 }
 
@@ -642,54 +562,47 @@ __device__ __forceinline__ void inside_sums_cell(const DeviceBatch& b, const Seq
 // CONTRAfold: they are folds of their own (inside_zr_pair2, the launch before this one).
 
 // CONTRAfold: sums_rightmost_basepairs_{external,multibranch} of cells (i, i+d) and
-// (i, i+d+1) (src/mccaskill_algo.rs:468-486).  Only pairs (i,k) contribute a term, so the
-// lane walks row i's list of canonical partners (k ascending, the reference's order)
-// instead of every k: 62 % fewer fold steps than the dense walk, same operations for the
-// terms that exist.  Lists are lane-private streams of 8-entry pieces.
+// (i, i+d+1) off one stream of sums_accessible(i, k) (src/mccaskill_algo.rs:468-486)
 __device__ __forceinline__ void inside_zr_pair2(const DeviceBatch& b, const Seq& q, uint32_t d,
-                                                uint32_t i, bool valid, const LseTab* tab) {
+                                                uint32_t i, const LseTab* tab) {
   const uint32_t n = q.n;
-  const uint32_t j = i + d;
-  const bool hasB = valid && j + 1 < n;
+  const bool hasB = i + d + 1 < n;
   const rnamc_fold_score_sets& f = b.params->contra;
   const float ebp = f.external_score_basepair, eun = f.external_score_unpair;
   const float mbp = f.multibranch_score_basepair, mun = f.multibranch_score_unpair;
-  const uint32_t base = valid ? q.rowoff[i] : 0u;
-  const uint32_t cnt = valid ? q.rowoff[i + 1] - base : 0u;  // multiple of 8
-  const uint4* __restrict__ kcol = reinterpret_cast<const uint4*>(q.rk + base);
-  const float4* __restrict__ acol = reinterpret_cast<const float4*>(q.m[M_W] + base);
+  const float* __restrict__ qa = q.m[M_QA];
   float eA = kNegInf, mA = kNegInf, eB = kNegInf, mB = kNegInf;
-  bool live = cnt > 0;
-  for (uint32_t r = 0; __ballot(live) != 0ull; r += 8) {
-    uint4 kk = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-    float4 x0 = make_float4(kNegInf, kNegInf, kNegInf, kNegInf), x1 = x0;
-    if (live) {
-      kk = kcol[r / 8];
-      x0 = acol[r / 4];
-      x1 = acol[r / 4 + 1];
-    }
-    const uint32_t kw[4] = {kk.x, kk.y, kk.z, kk.w};
-    const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+  // k = i + t; j - k = d - t for the first cell, d + 1 - t for the second
+  auto step = [&](float x, uint32_t t) {
+    const float ca = static_cast<float>(d - t), cb = static_cast<float>(d + 1 - t);
+    eA = lse(eA, x + ebp + eun * ca, tab);
+    eB = lse(eB, x + ebp + eun * cb, tab);
+    mA = lse(mA, x + mbp + mun * ca, tab);
+    mB = lse(mB, x + mbp + mun * cb, tab);
+  };
+  struct ABuf {
+    float xs[kU];
+  };
+  uint32_t t = pingpong<ABuf, kU, true>(
+      1u, d / kU,
+      [&](ABuf& B, uint32_t t0) {
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const uint32_t k = (kw[u >> 1] >> (16 * (u & 1))) & 0xFFFFu;
-      // k <= j: a term of the first cell; k <= j+1: of the second (absent otherwise)
-      const float xa = (k <= j) ? xs[u] : kNegInf;
-      const float xb = (k <= j + 1) ? xs[u] : kNegInf;
-      const float ca = static_cast<float>(j - k), cb = static_cast<float>(j + 1 - k);
-      eA = lse(eA, xa + ebp + eun * ca, tab);
-      eB = lse(eB, xb + ebp + eun * cb, tab);
-      mA = lse(mA, xa + mbp + mun * ca, tab);
-      mB = lse(mB, xb + mbp + mun * cb, tab);
-    }
-    // partners ascend: once the piece's last k is past j+1 (or the list ends) the lane is done
-    live = live && (r + 8 < cnt) && ((kw[3] >> 16) <= j + 1);
-  }
-  if (!valid) return;
+        for (int u = 0; u < kU; u++) B.xs[u] = ldu(qa + tri_off(n, t0 + u), i * 4u);
+      },
+      [&](const ABuf& B, uint32_t t0) {
+#pragma unroll
+        for (int u = 0; u < kU; u++) step(B.xs[u], t0 + u);
+      });
+  for (; t <= d; t++) step(qa[tri_off(n, t) + i], t);
   const uint32_t odA = tri_off(n, d) + i, odB = tri_off(n, d + 1) + i;
   q.m[M_ZRE][odA] = eA;
   q.m[M_ZRM][odA] = mA;
   if (!hasB) return;
+  {  // k = j + 1 of the second cell
+    const float x = qa[odB];
+    eB = lse(eB, x + ebp + eun * 0.f, tab);
+    mB = lse(mB, x + mbp + mun * 0.f, tab);
+  }
   q.m[M_ZRE][odB] = eB;
   q.m[M_ZRM][odB] = mB;
 }
@@ -1016,14 +929,10 @@ __global__ void __launch_bounds__(256) k_inside2(DeviceBatch b, uint32_t d, uint
   }
   if (bxr < blocks_sums) {
     const uint32_t i = bxr * blockDim.x + threadIdx.x;
-    if (!do_sums || d >= n) return;
+    if (!do_sums || d >= n || i >= n - d) return;
     if (ZR_ONLY) {
-      if (i - (threadIdx.x & 63u) >= n - d) return;  // whole wave past the diagonal
-      inside_zr_pair2(b, q, d, i, i < n - d, &tabs);
-      return;
-    }
-    if (i >= n - d) return;
-    {
+      inside_zr_pair2(b, q, d, i, &tabs);
+    } else {
       inside_sums_pair2<CONTRA>(b, q, d, i, &tabs);
     }
   } else {
@@ -1463,25 +1372,12 @@ __global__ void k_finalize(DeviceBatch b, uint32_t dmin_out) {
 // ----------------------------------------------------------------------------
 // launch wrappers (host)
 
-void launch_init(const DeviceBatch& b, bool contra, uint32_t nseq, uint32_t max_n, hipStream_t st) {
+void launch_init(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st) {
   const uint64_t elems = static_cast<uint64_t>(max_n) * (max_n + 1) / 2 * M_COUNT;
   uint32_t gx = static_cast<uint32_t>(std::min<uint64_t>((elems + 1023) / 1024, 512));
   if (gx == 0) gx = 1;
   hipLaunchKernelGGL(k_init, dim3(gx, nseq, 1), dim3(256), 0, st, b);
   hipLaunchKernelGGL(k_compact, dim3(max_n, nseq, 1), dim3(64), 0, st, b);
-  if (contra) {  // row lists of canonical partners (inside_zr_pair2)
-    hipLaunchKernelGGL(k_rowcount, dim3(max_n, nseq, 1), dim3(64), 0, st, b);
-    hipLaunchKernelGGL(k_rowscan, dim3(nseq, 1, 1), dim3(64), 0, st, b);
-    hipLaunchKernelGGL(k_rowfill, dim3(max_n, nseq, 1), dim3(64), 0, st, b);
-  }
-}
-
-// CONTRAfold: the W slot held the row lists' sums_accessible during the inside pass
-void launch_fill_w(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st) {
-  const uint64_t elems = static_cast<uint64_t>(max_n) * (max_n + 1) / 2;
-  uint32_t gx = static_cast<uint32_t>(std::min<uint64_t>((elems + 1023) / 1024, 512));
-  if (gx == 0) gx = 1;
-  hipLaunchKernelGGL(k_fill_w, dim3(gx, nseq, 1), dim3(256), 0, st, b);
 }
 
 // sums of diagonal d (if do_sums) and closing-pair block of diagonal d+1 (if do_pair)
