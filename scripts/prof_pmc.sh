@@ -12,8 +12,7 @@ for SET in \
  "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA" \
  "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE" \
  "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum" \
- "FETCH_SIZE" \
- "WRITE_SIZE" ; do
+; do
   i=$((i+1))
   rocprofv3 --pmc $SET --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/scripts/quick_timing.py $W > $OUT/run$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/run$i.log; }
 done
@@ -25,7 +24,14 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         kn = r["Kernel_Name"]
-        k = "k_outside" if "k_outside" in kn else "k_inside" if "k_inside" in kn else "other"
+        if "k_outside" in kn:
+            k = "k_outside_main" if ", 5>" in kn else "k_outside_tail" if ", 2>" in kn else "k_outside_small"
+        elif "k_inside2" in kn:
+            k = "k_inside2"
+        elif "k_inside" in kn or "k_pair_tail" in kn:
+            k = "k_inside_small"
+        else:
+            k = "other"
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
 with open(out + "/summary.txt", "w") as fh:
     for k, v in agg.items():
