@@ -4,18 +4,30 @@
 Contract (one JSON line from rank 0):
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+(`--gpus N` with N > 1 outside torchrun starts that launcher itself, as a fresh child
+process before anything touches the GPU, and relays its line.)
 
 A "step" is one pass of the hot path (inside + outside sweep + final map) over the
 whole workload, inputs already resident in HBM, outputs left in HBM.  The default
 workload is BASELINE.json's batch config: 10 000 synthetic RNAs of length 256..2048
 (SplitMix64, master seed 10000), Turner-2004-shaped synthetic tables, reference-order
-(bit-faithful) summation.  With N GPUs the batch is sharded by longest-processing-time
-over sum n(n^2-1)/6 (strong scaling: total work fixed); no data-path collective — the
-only communication is the barrier and the max-over-ranks of the step time.
+(bit-faithful) summation.  With N GPUs the batch is sharded in cost-balanced bands
+(strong scaling: total work fixed); no data-path collective — the only communication is
+the barrier and the max-over-ranks of the step time.
+
+Beside `value` (device-resident, as the contract asks) the line carries
+`value_with_transfers`: one pass through the host-buffer entry `rnamc_bpp_batch`
+(H2D + kernels + D2H — the unit SURVEY.md 8d defines), taken as the first warm-up pass.
+The per-kernel HIP-event timing behind `roofline` is taken in the LAST warm-up pass; after
+the timed steps the batch members that have committed oracle checksums
+(tests/golden/checksums_batch.json) are read back and compared (`parity_check`).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+T_START = time.time()
 
 
 def shard_lpt(costs, world):
@@ -68,15 +81,17 @@ def build_workload(name, batch_count):
 
 def outside_bytes(lengths, f, part="all"):
     """Algorithmic bytes of the outside sweep: L_d 8 B per (cell,k), L_e 12 B per (paired
-    cell,k), 8 B per enclosing-pair probe, 4 packed triangles written.  part "main" = the
-    roles of k_outside<.,5> (L_d, the probes, 2 triangles), "tail" = k_outside<.,2> (L_e)."""
+    cell,k), 8 B per enclosing-pair probe, 4 packed triangles written.  Parts by role:
+    "mb" probs_multibranch (L_d), "head" the 2-loop half of the pair probabilities,
+    "tail" their multibranch half (L_e); "main" = mb + head (one kernel when not split)."""
     from rna_algos_amd import workloads as W
     lengths = np.asarray(lengths, dtype=np.float64)
     T = W.pair_cost(lengths).sum()
     n2 = (lengths * lengths).sum()
-    main = 8.0 * T + 8.0 * 496.0 * f * n2 / 2.0 + 8.0 * n2 / 2.0
+    mb = 8.0 * T + 4.0 * n2 / 2.0
+    head = 8.0 * 496.0 * f * n2 / 2.0 + 4.0 * n2 / 2.0
     tail = 12.0 * f * T + 8.0 * n2 / 2.0
-    return {"all": main + tail, "main": main, "tail": tail}[part]
+    return {"all": mb + head + tail, "main": mb + head, "mb": mb, "head": head, "tail": tail}[part]
 
 
 def inside_bytes(lengths, f, contra, schedule="model"):
@@ -100,60 +115,107 @@ def pmc_traffic_per_launch(kernel, total_T, launches):
     """HBM bytes per launch of `kernel` from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate runs, scripts/prof_traffic.sh; FETCH_SIZE doubled as the gfx950 guide
     prescribes), scaled from that pass's workload to this one by sum n(n^2-1)/6.  None when the
-    profile is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic_batch1000.json")
+    profile is absent.  The newest round's file wins."""
+    for name in ("r02_traffic_batch1000.json", "r01_traffic_batch1000.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            t = json.load(open(path))
+            from rna_algos_amd import workloads as W
+            ref_T = float(W.pair_cost(W.batch_lengths(1000)).sum())
+            k = t[kernel]
+            return ((k["fetch_bytes_x2"] + k["write_bytes"]) * (total_T / ref_T) / max(launches, 1),
+                    "profiles/" + name)
+        except Exception:
+            continue
+    return None, None
+
+
+def golden_digest(packed):
+    """sha256 of the f32 bits with the libm-exp branch (p >= 0.9999) canonicalised, as
+    tests/make_golden.py computes it from the oracle."""
+    a = np.array(packed, dtype=np.float32, copy=True)
+    a[a >= 0.9999] = 1.0
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+def cpu_model():
     try:
-        t = json.load(open(path))
-        from rna_algos_amd import workloads as W
-        ref_T = float(W.pair_cost(W.batch_lengths(1000)).sum())
-        k = t[kernel]
-        return (k["fetch_bytes_x2"] + k["write_bytes"]) * (total_T / ref_T) / max(launches, 1)
-    except Exception:
-        return None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def usable_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
 
 
 def cpu_baseline(params, seqs, contra, budget_s):
-    """Oracle ("port" of the reference's CPU path) on a bounded, length-stratified sample,
-    one sequence per thread on all host cores (as the reference's thread pool does)."""
+    """Oracle ("port" of the reference's CPU path) on a bounded sample, one sequence per
+    thread on all usable host cores (as the reference's thread pool does).  Every thread gets
+    a sequence of (nearly) the SAME cost, so that all cores are busy for the whole wall time:
+    the `cores` sequences of the workload whose lengths are closest to the length whose cost
+    fits the budget."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     from rna_algos_amd import workloads as W
-    # a 1-GPU box's CPU share is 16 cores; never more threads than that
-    cores = min(os.cpu_count() or 1, 16)
+    cores = usable_cores()
     lens = np.array([len(s) for s in seqs])
-    # ~150 ns per (cell,k) per core for the dense row-major restatement: every thread gets
-    # one sequence whose cost fits the budget, taken at even strides of the length-sorted
-    # workload below that cost (the sample is stated in the result)
-    per_core_T = budget_s / 150e-9
-    fits = np.nonzero(W.pair_cost(lens) <= per_core_T)[0]
-    if fits.size:
-        order = fits[np.argsort(lens[fits])]
-        k = min(cores, order.size)
-        pick = order[np.linspace(0, order.size - 1, k).astype(int)]
+    # ~150 ns per (cell,k) per core for the dense row-major restatement
+    n_target = (6.0 * budget_s / 150e-9) ** (1.0 / 3.0)
+    if len(seqs) >= cores:
+        pick = np.argsort(np.abs(lens - n_target), kind="stable")[:cores]
         sample = [seqs[i] for i in pick]
     else:
-        # a single long sequence (n = 4096): time a prefix whose cost fits the budget
-        m = int((per_core_T * 6) ** (1 / 3))
-        sample = [seqs[int(np.argmin(lens))][:m]]
+        # a single long sequence (n = 4096): every core times the same prefix whose cost fits
+        m = int(min(n_target, lens.min()))
+        sample = [seqs[int(np.argmin(lens))][:m]] * cores
     t0 = time.time()
-    O.bpp_batch(params.ptr, sample, contra, False, n_threads=min(cores, len(sample)),
-                want_bpp=False)
+    O.bpp_batch(params.ptr, sample, contra, False, n_threads=len(sample), want_bpp=False)
     dt = time.time() - t0
     nt = int(sum(len(s) for s in sample))
-    T = float(W.pair_cost(np.array([len(s) for s in sample])).sum())
+    slens = np.array([len(s) for s in sample])
+    T = float(W.pair_cost(slens).sum())
     T_all = float(W.pair_cost(lens).sum())
     return {
         # scaled to the metric's unit: the workload's nt/s if the whole of it ran at the
         # sample's rate per (cell,k) iteration (cost model sum n(n^2-1)/6)
         "value": float(lens.sum()) / (dt * T_all / T), "unit": "nt/s",
-        "cores": int(min(cores, len(sample))), "kind": "port",
-        "sample": f"{len(sample)} sequences (lengths {sorted(len(s) for s in sample)}) of the "
-                  f"workload, one per thread, {dt:.1f} s wall; extrapolated by sum n(n^2-1)/6. "
-                  f"The port is faster than the Rust reference would be (dense arrays, no "
-                  f"twoloop_scores hash map)",
+        "cores": int(len(sample)), "kind": "port",
+        "sample": f"{len(sample)} sequences of the workload with lengths {int(slens.min())}.."
+                  f"{int(slens.max())} (equal cost per thread), one per thread, {dt:.1f} s wall; "
+                  f"extrapolated to the workload by sum n(n^2-1)/6.  The port is faster than the "
+                  f"Rust reference would be (dense arrays, no twoloop_scores hash map)",
+        "os_cpu_count": os.cpu_count(), "usable_cores": cores, "cpu_model": cpu_model(),
         "sample_nt_per_s": nt / dt,
-        "ns_per_cell_k_all_cores": dt * 1e9 / T,
+        "ns_per_cell_k_per_core": dt * 1e9 * len(sample) / T,
     }
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def relaunch_under_torchrun(args):
+    """--gpus N > 1 without a torchrun environment: start the launcher as a CHILD process
+    (nothing in this process has touched the GPU yet) and relay its output."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print(f"bench.py: --gpus {args.gpus} outside torchrun: launching {' '.join(cmd[1:8])} ...",
+          file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -174,30 +236,47 @@ def main():
     ap.add_argument("--group-max-nt", type=int, default=0)
     ap.add_argument("--group-ws-gb", type=int, default=0)
     ap.add_argument("--param-seed", type=int, default=1)
-    ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
-                    help="skip the extra pass that times every outside kernel with HIP events")
+                    help="no per-kernel HIP events in the last warm-up pass")
     ap.add_argument("--no-n4096", action="store_true",
                     help="skip the single n=4096 sequence (second half of BASELINE.json's metric)")
+    ap.add_argument("--no-transfers", action="store_true",
+                    help="skip the host-buffer pass (value_with_transfers)")
+    ap.add_argument("--time-budget-s", type=float, default=540.0,
+                    help="wall-clock budget of the whole run: optional legs (transfers pass, "
+                         "n=4096, CPU baseline) are dropped, with a note in the line, when the "
+                         "W + K passes would not leave room for them")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no device work: exercises launcher, sharding, barrier and the "
+                         "max-over-ranks reduction (CPU test of the N > 1 path, with gloo)")
+    ap.add_argument("--set", action="append", default=[], metavar="KNOB=VALUE",
+                    help="rnamc_ctx_set knob (tuning experiments)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.rehearse_shard:
+        sys.exit(relaunch_under_torchrun(args))
 
     import torch
     import torch.distributed as dist
     from rna_algos_amd import workloads as W
-    from rna_algos_amd.utils import FoldScoreSets
-    from rna_algos_amd.mccaskill_algo import Context
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: refusing to report a "
+                  f"{world}-rank run as {args.gpus} GPUs", file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    if args.gpus != world and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group("gloo")
     contra = args.model == "contra"
 
     seqs, label = build_workload(args.workload, args.batch_count)
@@ -219,6 +298,56 @@ def main():
     out_offsets = np.zeros(len(my_seqs) + 1, dtype=np.uint64)
     np.cumsum(lens * (lens + np.uint64(1)) // np.uint64(2), out=out_offsets[1:])
 
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        dev_t = torch.device(f"cuda:{local_rank}") if args.backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([x], dtype=torch.float64, device=dev_t)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    total_nt = int(lens_all.sum()) if len(seqs) >= world else int(lens_all.sum()) * world
+    base = {
+        "metric": "nucleotides/sec (batch)" if args.workload == "batch10k" else "nucleotides/sec",
+        "unit": "nt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+    }
+
+    if args.dry_run:
+        # the N > 1 plumbing without a device: partition, barrier, max-reduce of a step time
+        barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (rank + 1))
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        cnt = len(my_seqs)
+        if world > 1:
+            c = torch.tensor([cnt, int(lens.sum())], dtype=torch.int64)
+            if args.backend == "nccl":
+                c = c.to(f"cuda:{local_rank}")
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            cnt, nt_sum = (int(x) for x in c.tolist())
+            assert len(seqs) < world or (cnt == len(seqs) and nt_sum == int(lens_all.sum())), \
+                "shards do not partition the batch"
+        if rank == 0:
+            base.update({"value": 0.0, "ms_per_step": elapsed * 1e3, "dry_run": True,
+                         "config": {"workload": label, "sequences_all_ranks": cnt,
+                                    "sharding": f"{args.shard}, {world} rank(s), backend "
+                                                f"{args.backend}"}})
+            print(json.dumps(base), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    from rna_algos_amd.utils import FoldScoreSets
+    from rna_algos_amd.mccaskill_algo import Context
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
     params = FoldScoreSets.synthetic(args.param_seed)
     ctx = Context(params, device=local_rank)
     ctx.set("profile", 1)
@@ -228,9 +357,13 @@ def main():
         ctx.set("group_max_nt", args.group_max_nt)
     if args.group_ws_gb:
         ctx.set("group_ws_bytes", args.group_ws_gb << 30)
+    for kv in args.set:
+        k, v = kv.split("=")
+        ctx.set(k, int(v))
 
     # inputs resident in HBM before the timed region; outputs stay in HBM
-    d_bases = torch.from_numpy(np.concatenate(my_seqs)).to(dev)
+    h_bases = np.concatenate(my_seqs)
+    d_bases = torch.from_numpy(h_bases).to(dev)
     d_out = torch.empty(int(out_offsets[-1]), dtype=torch.float32, device=dev)
     d_logz = torch.empty(len(my_seqs), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
@@ -239,18 +372,75 @@ def main():
         ctx.bpp_batch_device(len(my_seqs), d_bases.data_ptr(), offsets, contra, False,
                              d_out.data_ptr(), out_offsets, d_logz.data_ptr(), stream)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    notes = []
+    ms_main = ms_tail = ms_small = ms_head = 0.0
+    l_main = l_tail = l_small = l_head = 0
+    with_transfers = None
+    pass_s = None  # measured duration of one pass (first warm-up)
 
-    for _ in range(args.warmup):
+    passes_due = args.steps + args.warmup
+
+    def room_for(extra_s):
+        """is there room for an optional leg of `extra_s` seconds beside the passes still due?"""
+        if pass_s is None:
+            return True
+        return (time.time() - T_START) + passes_due * pass_s + extra_s <= args.time_budget_s
+
+    for w in range(args.warmup):
+        last = w == args.warmup - 1
+        passes_due = args.steps + args.warmup - w - 1
+        want_tr = (w == 0 and args.warmup >= 2 and not args.no_transfers and rank == 0
+                   and world == 1 and not args.rehearse_shard)
+        if want_tr:
+            # first warm-up pass through the host-buffer entry: H2D + kernels + D2H.  Host
+            # buffers are allocated and touched before the clock starts (the caller owns them).
+            h_out = np.empty(int(out_offsets[-1]), dtype=np.float32)
+            h_out[::1024] = 0.0  # touch every page
+            h_logz = np.empty(len(my_seqs), dtype=np.float32)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.bpp_batch_into(h_bases, offsets, contra, False, h_out, out_offsets, h_logz)
+            dt = time.perf_counter() - t0
+            with_transfers = {"value": float(lens.sum()) / dt, "unit": "nt/s", "s": dt,
+                              "what": "one pass of rnamc_bpp_batch (pageable host buffers in, "
+                                      "host buffers out): H2D + kernels + D2H"}
+            pass_s = dt
+            del h_out
+            continue
+        if last and rank == 0 and not args.no_kernel_timing:
+            # per-kernel durations for the roofline: a pair of HIP events around every
+            # outside-sweep kernel, on the stream it is launched on (costs ~2 %: warm-up only)
+            ctx.set("profile", 2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        pass_s = dt if pass_s is None else min(pass_s, dt)
+        if last and rank == 0 and not args.no_kernel_timing:
+            st = ctx.stats()
+            ctx.set("profile", 1)
+            ms_main, ms_tail, ms_small = (st["ms_outside_main"], st["ms_outside_tail"],
+                                          st["ms_outside_small"])
+            l_main, l_tail, l_small = (st["launches_outside_main"], st["launches_outside_tail"],
+                                       st["launches_outside_small"])
+            ms_head, l_head = st.get("ms_outside_head", 0.0), st.get("launches_outside_head", 0)
+    steps = args.steps
+    if pass_s is not None:
+        # last resort against a driver-side timeout (a killed bench is an unmeasured round):
+        # fewer timed steps than asked for, reported as such
+        fit = int((args.time_budget_s - (time.time() - T_START) - 5.0) / pass_s)
+        fit = max_over_ranks(float(-fit)) * -1.0  # the smallest fit over ranks
+        if fit < steps:
+            steps = max(1, int(fit))
+            notes.append(f"time budget {args.time_budget_s:.0f} s: timed {steps} of the "
+                         f"{args.steps} steps asked for ({pass_s:.1f} s per pass)")
     torch.cuda.synchronize()
     barrier()
-    ms_in = ms_out = ms_main = ms_tail = ms_small = 0.0
-    l_in = l_out = l_main = l_tail = l_small = 0
+    ms_in = ms_out = 0.0
+    l_in = l_out = 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
         st = ctx.stats()  # event-timed sweeps of this step (the call synchronised its stream)
         ms_in += st["ms_inside"]
@@ -259,64 +449,72 @@ def main():
         l_out += st["launches_outside"]
     torch.cuda.synchronize()
     barrier()
-    elapsed = time.perf_counter() - t0
-    # one more pass, outside the timed region, with a pair of HIP events around every
-    # outside-sweep kernel (on the stream it is launched on): per-kernel durations for the
-    # roofline of the dominant kernel.  Those event records cost ~2 %, so the timed steps
-    # above run without them.
-    if rank == 0 and not args.no_kernel_timing:
-        ctx.set("profile", 2)
-        step()
-        st = ctx.stats()
-        ctx.set("profile", 1)
-        ms_main, ms_tail, ms_small = (st["ms_outside_main"], st["ms_outside_tail"],
-                                      st["ms_outside_small"])
-        l_main, l_tail, l_small = (st["launches_outside_main"], st["launches_outside_tail"],
-                                   st["launches_outside_small"])
-        torch.cuda.synchronize()
-    barrier()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    pass_s = elapsed / max(steps, 1)
+    passes_due = 0
 
-    # sanity: the result is a probability matrix (cheap, outside the timed region)
+    # parity, outside the timed region: batch members with committed oracle checksums
+    checked = failed = 0
+    if args.workload == "batch10k" and args.param_seed == 1:
+        try:
+            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "checksums_batch.json")))["cases"]
+        except OSError:
+            gold = {}
+        where = {int(g): x for x, g in enumerate(mine)}
+        for key, info in gold.items():
+            idx = int(key.split("_")[0][len("batch"):])
+            if key.endswith("contra") != contra or idx not in where or idx >= args.batch_count:
+                continue
+            x = where[idx]
+            got = d_out[int(out_offsets[x]):int(out_offsets[x + 1])].cpu().numpy()
+            checked += 1
+            if golden_digest(got) != info["sha256"] or len(my_seqs[x]) != info["n"]:
+                failed += 1
     probe = d_out[: min(d_out.numel(), 1 << 22)]
     pres = probe[probe >= -0.5]
     assert pres.numel() > 0 and float(pres.min()) >= -0.001 and float(pres.max()) < 1.05
     assert bool(torch.isfinite(d_logz).all())
+    if failed:
+        print(f"bench.py: {failed} of {checked} golden batch members differ from the oracle's "
+              f"checksum", file=sys.stderr)
+        sys.exit(3)
 
     if rank == 0:
-        total_nt = int(lens_all.sum()) if len(seqs) >= world else int(lens_all.sum()) * world
-        steps = max(args.steps, 1)
         f = float(np.mean([W.paired_fraction(s) for s in my_seqs[:: max(1, len(my_seqs) // 8)]]))
-        b_out = outside_bytes(lens.astype(np.float64), f)
-        b_main = outside_bytes(lens.astype(np.float64), f, "main")
-        b_tail = outside_bytes(lens.astype(np.float64), f, "tail")
-        total_T = float(W.pair_cost(lens.astype(np.float64)).sum())
+        lf = lens.astype(np.float64)
+        b_out = outside_bytes(lf, f)
+        total_T = float(W.pair_cost(lf).sum())
+        # dominant kernel of the outside sweep: with the 2-loop half in a kernel of its own
+        # (LDS-staged probe windows) the "main" kernel is probs_multibranch alone
+        split_head = l_head > 0
+        b_main = outside_bytes(lf, f, "mb" if split_head else "main")
+        b_tail = outside_bytes(lf, f, "tail")
+        b_head = outside_bytes(lf, f, "head")
         if l_main == 0:
             # nothing was large enough to split (single sequences): all roles ran in
             # k_outside<.,7>, which then is the dominant kernel
             b_main, ms_main, l_main = b_out, ms_small, l_small
-        b_in = inside_bytes(lens.astype(np.float64), f, contra, "two_diagonal")
-        b_in_model = inside_bytes(lens.astype(np.float64), f, contra, "model")
-        avg_out_ms = ms_out / max(l_out, 1)
-        avg_in_ms = ms_in / max(l_in, 1)
+        b_in = inside_bytes(lf, f, contra, "two_diagonal")
+        b_in_model = inside_bytes(lf, f, contra, "model")
         ach_out = b_out * steps / (ms_out * 1e-3) / 1e9 if ms_out > 0 else 0.0
         ach_in = b_in * steps / (ms_in * 1e-3) / 1e9 if ms_in > 0 else 0.0
-        res = {
-            "metric": "nucleotides/sec (batch)" if args.workload == "batch10k" else "nucleotides/sec",
+
+        def roof(kernel, b, ms, launches, pmc_key, **extra):
+            ach = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            traffic, src = (pmc_traffic_per_launch(pmc_key, total_T, launches)
+                            if args.workload == "batch10k" and not contra and pmc_key else (None, None))
+            r = {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                 "traffic_source": src, "algorithmic_bytes_per_launch": b / max(launches, 1),
+                 "avg_launch_ms": ms / max(launches, 1), "launches_per_step": launches}
+            r.update(extra)
+            return r
+
+        res = dict(base)
+        res.update({
             "value": total_nt * steps / elapsed,
-            "unit": "nt/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
+            "steps": steps,
             "ms_per_step": elapsed * 1e3 / steps,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
             "config": {
                 "workload": label,
                 "model": "Turner-2004-shaped synthetic tables" if not contra
@@ -330,43 +528,27 @@ def main():
                 "sequences_rank0": len(my_seqs),
                 "paired_fraction_f": f,
             },
+            "parity_check": (f"{checked}/{checked} golden members (sha256 of the whole matrix "
+                             f"against the oracle's, tests/golden/checksums_batch.json)")
+            if checked else "none of the golden members is in this run",
+            "value_with_transfers": with_transfers["value"] if with_transfers else None,
+            "with_transfers": with_transfers,
             # the dominant kernel by GPU time (rocprofv3 --stats): per-kernel accounting, HIP
-            # events around each of its launches on its own stream.  Its few small-launch
-            # siblings (k_outside<.,7>, < 1 % of the time) do the same roles on the first
-            # diagonals; their bytes are left in, which costs the figure a fraction of a percent
-            "roofline": {
-                "kernel": ("k_outside<.,5> (probs_multibranch + 2-loop half of the pair "
-                           "probabilities, one launch per anti-diagonal)") if l_tail else
-                          "k_outside<.,7> (outside sweep, all roles, one launch per anti-diagonal)",
-                "bound": "hbm",
-                "achieved": b_main / (ms_main * 1e-3) / 1e9 if ms_main > 0 else 0.0,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": (b_main / (ms_main * 1e-3) / 1e9 if ms_main > 0 else 0.0) / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_per_launch("k_outside_main", total_T, l_main)
-                if args.workload == "batch10k" and not contra else None,
-                "traffic_source": "profiles/r01_traffic_batch1000.json (separate --pmc passes, scaled by "
-                                  "sum n(n^2-1)/6)",
-                "algorithmic_bytes_per_launch": b_main / max(l_main, 1),
-                "avg_launch_ms": ms_main / max(l_main, 1),
-                "launches_per_step": l_main,
-                "note": "runs beside k_outside<.,2> (second stream): both share the chip",
-            },
-            "roofline_tail": {
-                "kernel": "k_outside<.,2> (multibranch half of the pair probabilities)",
-                "bound": "hbm",
-                "achieved": b_tail / (ms_tail * 1e-3) / 1e9 if ms_tail > 0 else 0.0,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (b_tail / (ms_tail * 1e-3) / 1e9 if ms_tail > 0 else 0.0) / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_per_launch("k_outside_tail", total_T, l_tail)
-                if args.workload == "batch10k" and not contra else None,
-                "algorithmic_bytes_per_launch": b_tail / max(l_tail, 1),
-                "avg_launch_ms": ms_tail / max(l_tail, 1),
-                "launches_per_step": l_tail,
-            },
+            # events around each of its launches on its own stream, taken in the last warm-up
+            # pass.  Its few small-launch siblings (k_outside<.,7>, < 1 % of the time) do the
+            # same roles on the first diagonals; their bytes are left in
+            "roofline": roof(
+                ("k_outside<.,1> (probs_multibranch, one launch per anti-diagonal)" if split_head else
+                 "k_outside<.,5> (probs_multibranch + 2-loop half of the pair probabilities, one "
+                 "launch per anti-diagonal)") if l_tail else
+                "k_outside<.,7> (outside sweep, all roles, one launch per anti-diagonal)",
+                b_main, ms_main, l_main, "k_outside_main",
+                note="runs beside the pair-probability kernels (other streams): they share the chip"),
+            "roofline_tail": roof("k_outside<.,2> (multibranch half of the pair probabilities)",
+                                  b_tail, ms_tail, l_tail, "k_outside_tail"),
             "roofline_outside_sweep": {
-                "what": "both kernels together: algorithmic bytes of the whole outside sweep over its "
-                        "event-timed duration",
+                "what": "all outside kernels together: algorithmic bytes of the whole outside "
+                        "sweep over its event-timed duration",
                 "bound": "hbm", "achieved": ach_out, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach_out / HBM_PEAK_GBS,
                 "ms_per_step": ms_out / steps,
@@ -377,39 +559,58 @@ def main():
             "roofline_inside": {
                 "kernel": "k_inside2 / k_inside (inside sweep)", "bound": "hbm", "achieved": ach_in,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_in / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_per_launch("k_inside", total_T, l_in / steps)
+                "traffic": pmc_traffic_per_launch("k_inside", total_T, l_in / steps)[0]
                 if args.workload == "batch10k" and not contra else None,
-                "avg_launch_ms": avg_in_ms, "launches_per_step": l_in // steps,
+                "avg_launch_ms": ms_in / max(l_in, 1), "launches_per_step": l_in // steps,
+                "ms_per_step": ms_in / steps,
                 "note": "bytes of the two-diagonal schedule (one lane folds two cells off one stream "
                         "of the row operands: 6 B per (cell,k)); by SURVEY 8d's streamed-operand "
                         "model (16 B per (cell,k)) the same sweep scores model_achieved",
                 "model_achieved": b_in_model * steps / (ms_in * 1e-3) / 1e9 if ms_in > 0 else 0.0,
             },
-        }
+        })
+        if split_head:
+            res["roofline_head"] = roof(
+                "k_head_out (2-loop half of the pair probabilities, probe windows staged in LDS)",
+                b_head, ms_head, l_head, "k_outside_head")
         if args.workload != "batch10k":
             res["ms_per_seq"] = elapsed * 1e3 / steps
         elif world == 1 and not args.no_n4096 and not args.rehearse_shard:
             # the other half of the metric: ms per sequence at n = 4096 (BASELINE.json
-            # configs[2]: Turner), one warm-up + one timed call, device-resident
-            s4 = W.synthetic_seq(4096, 4096)
-            b4 = torch.from_numpy(s4).to(dev)
-            o4 = torch.empty(4096 * 4097 // 2, dtype=torch.float32, device=dev)
-            z4 = torch.empty(1, dtype=torch.float32, device=dev)
-            off4 = np.array([0, 4096], dtype=np.uint64)
-            oo4 = np.array([0, 4096 * 4097 // 2], dtype=np.uint64)
-            for k in range(2):
+            # configs[2]: Turner), ONE timed call, device-resident (the median of >= 5 after a
+            # warm-up is `--workload n4096 --steps 5 --warmup 1`, profiles/)
+            if room_for(6.0 + (0 if args.no_cpu_baseline else args.cpu_budget_s + 3)):
+                s4 = W.synthetic_seq(4096, 4096)
+                b4 = torch.from_numpy(s4).to(dev)
+                o4 = torch.empty(4096 * 4097 // 2, dtype=torch.float32, device=dev)
+                z4 = torch.empty(1, dtype=torch.float32, device=dev)
+                off4 = np.array([0, 4096], dtype=np.uint64)
+                oo4 = np.array([0, 4096 * 4097 // 2], dtype=np.uint64)
                 torch.cuda.synchronize()
                 t4 = time.perf_counter()
                 ctx.bpp_batch_device(1, b4.data_ptr(), off4, contra, False, o4.data_ptr(), oo4,
                                      z4.data_ptr(), stream)
                 torch.cuda.synchronize()
-                t4 = time.perf_counter() - t4
-            res["ms_per_seq_n4096"] = t4 * 1e3
-            res["n4096_note"] = ("single n=4096 sequence, same tables: a lock-step group of one is "
-                                 "bound by the sequential fold chains the reference's summation "
-                                 "order dictates (2 x 8.4 M dependent steps), not by HBM")
+                res["ms_per_seq_n4096"] = (time.perf_counter() - t4) * 1e3
+                st4 = ctx.stats()
+                res["n4096_note"] = (
+                    f"single n=4096 sequence, same tables, one call (inside {st4['ms_inside']:.0f} ms"
+                    f", outside {st4['ms_outside']:.0f} ms): a lock-step group of one is bound by "
+                    f"the sequential fold chains the reference's summation order dictates "
+                    f"(n^2/2 = 8.4 M dependent steps inside, 3 n^2/2 = 25 M outside), not by HBM")
+            else:
+                notes.append("n=4096 leg skipped: time budget")
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(params, my_seqs, contra, args.cpu_budget_s)
+            if room_for(args.cpu_budget_s + 3):
+                res["cpu_baseline"] = cpu_baseline(params, my_seqs, contra, args.cpu_budget_s)
+            else:
+                notes.append("cpu_baseline leg skipped: time budget")
+                res["cpu_baseline"] = None
+        if steps != args.steps:
+            res["steps_requested"] = args.steps
+        if notes:
+            res["notes"] = notes
+        res["wall_s"] = time.time() - T_START
         print(json.dumps(res), flush=True)
     ctx.close()
     if world > 1:

@@ -1,0 +1,214 @@
+// dump_tables.rs — pins the oracle.  A maintainer with cargo runs this ONCE against the
+// UNMODIFIED reference crate (rna-algos 0.1.37 + rna-ss-params 0.1, no librnamc, no GPU):
+//
+//     cp bindings/rust/dump_tables.rs <rna-algos checkout>/src/bin/dump_tables.rs
+//     cargo run --release --bin dump_tables -- assets/sampled_trnas.fa OUT_DIR
+//
+// and commits the two files it writes under tests/golden/ of this repository:
+//   real_tables.tbl    every table the path reads, in librnamc's table-file format
+//                      (rnamc_params_load; 16-byte header {"RNAMCTBL", abi u32, bytes u32} +
+//                      the rnamc_params struct of include/rnamc.h, little-endian)
+//   real_goldens.bin   base-pairing probability matrices of the REFERENCE CPU PATH
+//                      (src/mccaskill_algo.rs:247-280) for every record of the FASTA under
+//                      {Turner, CONTRAfold, CONTRAfold + short hairpins}, plus two seeded
+//                      random sequences (n = 200, 400)
+// tests/test_real_tables.py picks both up when present: the CPU oracle and the HIP path must
+// then reproduce the goldens (bit-for-bit; the north_star's bar is 1e-6 relative), which is
+// the only thing that moves "parity" from unpinned to pinned.
+//
+// The struct layout is written field by field in the order of include/rnamc.h;
+// tests/test_rust_shim_cpu.py parses the FIELD ORDER table below and checks names, counts
+// and byte offsets against rnamc_params_field() of the built library.
+extern crate rna_algos;
+
+use rna_algos::mccaskill_algo::*;
+use rna_algos::utils::*;
+use std::io::Write;
+
+const RNAMC_ABI_VERSION: u32 = 2;
+const MAX_SPECIAL: usize = 64; // RNAMC_MAX_SPECIAL_HAIRPINS
+const SPECIAL_W: usize = 16; // RNAMC_MAX_SPECIAL_HAIRPIN_LEN
+
+fn flat<A>(a: &A) -> Vec<f32> {
+  unsafe { std::slice::from_raw_parts(a as *const A as *const f32, std::mem::size_of::<A>() / 4) }.to_vec()
+}
+
+struct Block {
+  bytes: Vec<u8>,
+}
+impl Block {
+  fn f32s(&mut self, _name: &str, count: usize, v: Vec<f32>) {
+    assert_eq!(v.len(), count, "shape of {}", _name);
+    for x in v {
+      self.bytes.extend_from_slice(&x.to_le_bytes());
+    }
+  }
+  fn u32(&mut self, x: u32) {
+    self.bytes.extend_from_slice(&x.to_le_bytes());
+  }
+}
+
+fn params_block(f: &FoldScoreSets) -> Vec<u8> {
+  let mut b = Block { bytes: Vec::new() };
+  // header: abi_version, struct_bytes (patched below), table_id
+  b.u32(RNAMC_ABI_VERSION);
+  b.u32(0);
+  b.bytes.extend_from_slice(&0x5245414c00000001u64.to_le_bytes()); // "REAL" | dump format 1
+  // FIELD ORDER BEGIN (name, element count) — struct rnamc_turner_scores
+  b.f32s("turner.hairpin_scores_init", 31, flat(&HAIRPIN_SCORES_INIT));
+  b.f32s("turner.terminal_mismatch_scores_hairpin", 256, flat(&TERMINAL_MISMATCH_SCORES_HAIRPIN));
+  b.f32s("turner.stack_scores", 256, flat(&STACK_SCORES));
+  b.f32s("turner.bulge_scores_init", 31, flat(&BULGE_SCORES_INIT));
+  b.f32s("turner.interior_scores_init", 31, flat(&INTERIOR_SCORES_INIT));
+  b.f32s("turner.interior_scores_1x1", 4096, flat(&INTERIOR_SCORES_1X1));
+  b.f32s("turner.interior_scores_1x2", 16384, flat(&INTERIOR_SCORES_1X2));
+  b.f32s("turner.interior_scores_2x2", 65536, flat(&INTERIOR_SCORES_2X2));
+  b.f32s("turner.terminal_mismatch_scores_1xmany", 256, flat(&TERMINAL_MISMATCH_SCORES_1XMANY));
+  b.f32s("turner.terminal_mismatch_scores_2x3", 256, flat(&TERMINAL_MISMATCH_SCORES_2X3));
+  b.f32s("turner.terminal_mismatch_scores_interior", 256, flat(&TERMINAL_MISMATCH_SCORES_INTERIOR));
+  b.f32s("turner.terminal_mismatch_scores_multibranch", 256, flat(&TERMINAL_MISMATCH_SCORES_MULTIBRANCH));
+  b.f32s("turner.dangling_scores_5prime", 64, flat(&DANGLING_SCORES_5PRIME));
+  b.f32s("turner.dangling_scores_3prime", 64, flat(&DANGLING_SCORES_3PRIME));
+  b.f32s("turner.helix_augu_end_penalty", 1, vec![HELIX_AUGU_END_PENALTY]);
+  b.f32s("turner.coeff_hairpin_len_extrapolation", 1, vec![COEFF_HAIRPIN_LEN_EXTRAPOLATION]);
+  b.f32s("turner.ninio_coeff", 1, vec![NINIO_COEFF]);
+  b.f32s("turner.ninio_max", 1, vec![NINIO_MAX]);
+  b.f32s("turner.init_multibranch_base", 1, vec![INIT_MULTIBRANCH_BASE]);
+  b.f32s("turner.coeff_num_branches", 1, vec![COEFF_NUM_BRANCHES]);
+  // HAIRPIN_SCORES_SPECIAL (src/utils.rs:198-205): scores, sequences, lengths, count
+  let n_special = HAIRPIN_SCORES_SPECIAL.len();
+  assert!(n_special <= MAX_SPECIAL, "RNAMC_MAX_SPECIAL_HAIRPINS");
+  let mut scores = vec![0f32; MAX_SPECIAL];
+  let mut seqs = vec![0u8; MAX_SPECIAL * SPECIAL_W];
+  let mut lens = vec![0u8; MAX_SPECIAL];
+  for (x, (hairpin, score)) in HAIRPIN_SCORES_SPECIAL.iter().enumerate() {
+    assert!(hairpin.len() <= SPECIAL_W, "RNAMC_MAX_SPECIAL_HAIRPIN_LEN");
+    for (y, &base) in hairpin.iter().enumerate() {
+      seqs[x * SPECIAL_W + y] = base as u8;
+    }
+    lens[x] = hairpin.len() as u8;
+    scores[x] = *score;
+  }
+  b.f32s("turner.special_hairpin_scores", 64, scores);
+  b.bytes.extend_from_slice(&seqs);
+  b.bytes.extend_from_slice(&lens);
+  b.u32(n_special as u32);
+  b.u32(MIN_HAIRPIN_LEN as u32);
+  b.u32(MAX_HAIRPIN_LEN_EXTRAPOLATION as u32);
+  b.u32(MIN_HAIRPIN_LEN_EXTRAPOLATION as u32);
+  // struct rnamc_fold_score_sets: the set as FoldScoreSets::new(0.).transfer() leaves it
+  b.f32s("contra.hairpin_scores_len", 31, flat(&f.hairpin_scores_len));
+  b.f32s("contra.bulge_scores_len", 30, flat(&f.bulge_scores_len));
+  b.f32s("contra.interior_scores_len", 29, flat(&f.interior_scores_len));
+  b.f32s("contra.interior_scores_symmetric", 15, flat(&f.interior_scores_symmetric));
+  b.f32s("contra.interior_scores_asymmetric", 28, flat(&f.interior_scores_asymmetric));
+  b.f32s("contra.stack_scores", 256, flat(&f.stack_scores));
+  b.f32s("contra.terminal_mismatch_scores", 256, flat(&f.terminal_mismatch_scores));
+  b.f32s("contra.dangling_scores_left", 64, flat(&f.dangling_scores_left));
+  b.f32s("contra.dangling_scores_right", 64, flat(&f.dangling_scores_right));
+  b.f32s("contra.helix_close_scores", 16, flat(&f.helix_close_scores));
+  b.f32s("contra.basepair_scores", 16, flat(&f.basepair_scores));
+  b.f32s("contra.interior_scores_explicit", 16, flat(&f.interior_scores_explicit));
+  b.f32s("contra.bulge_scores_0x1", 4, flat(&f.bulge_scores_0x1));
+  b.f32s("contra.interior_scores_1x1", 16, flat(&f.interior_scores_1x1));
+  b.f32s("contra.multibranch_score_base", 1, vec![f.multibranch_score_base]);
+  b.f32s("contra.multibranch_score_basepair", 1, vec![f.multibranch_score_basepair]);
+  b.f32s("contra.multibranch_score_unpair", 1, vec![f.multibranch_score_unpair]);
+  b.f32s("contra.external_score_basepair", 1, vec![f.external_score_basepair]);
+  b.f32s("contra.external_score_unpair", 1, vec![f.external_score_unpair]);
+  b.f32s("contra.hairpin_scores_len_cumulative", 31, flat(&f.hairpin_scores_len_cumulative));
+  b.f32s("contra.bulge_scores_len_cumulative", 30, flat(&f.bulge_scores_len_cumulative));
+  b.f32s("contra.interior_scores_len_cumulative", 29, flat(&f.interior_scores_len_cumulative));
+  b.f32s("contra.interior_scores_symmetric_cumulative", 15, flat(&f.interior_scores_symmetric_cumulative));
+  b.f32s("contra.interior_scores_asymmetric_cumulative", 28, flat(&f.interior_scores_asymmetric_cumulative));
+  // FIELD ORDER END
+  while b.bytes.len() % 8 != 0 {
+    b.bytes.push(0); // tail padding of a struct with a uint64_t member
+  }
+  let total = b.bytes.len() as u32;
+  b.bytes[4..8].copy_from_slice(&total.to_le_bytes());
+  // the compile-time limits of librnamc (include/rnamc.h) must be the crate's
+  assert_eq!(MAX_2LOOP_LEN, 30, "RNAMC_MAX_2LOOP_LEN");
+  assert_eq!(MAX_LOOP_LEN, 30, "RNAMC_MAX_LOOP_LEN");
+  assert_eq!(MIN_SPAN_HAIRPIN_CLOSE, 5, "RNAMC_MIN_SPAN_HAIRPIN_CLOSE");
+  assert_eq!(MAX_INTERIOR_EXPLICIT, 4, "RNAMC_MAX_INTERIOR_EXPLICIT");
+  assert_eq!(MAX_INTERIOR_SYMMETRIC, 15, "RNAMC_MAX_INTERIOR_SYMMETRIC");
+  assert_eq!(MAX_INTERIOR_ASYMMETRIC, 28, "RNAMC_MAX_INTERIOR_ASYMMETRIC");
+  b.bytes
+}
+
+// SplitMix64, base = top 2 bits (rna_algos_amd/workloads.py: synthetic_seq)
+fn synthetic_seq(n: usize, seed: u64) -> Seq {
+  let mut state = seed;
+  (0..n)
+    .map(|_| {
+      state = state.wrapping_add(0x9E3779B97F4A7C15);
+      let mut z = state;
+      z = (z ^ (z >> 30)).wrapping_mul(0xBF58476D1CE4E5B9);
+      z = (z ^ (z >> 27)).wrapping_mul(0x94D049BB133111EB);
+      z ^= z >> 31;
+      (z >> 62) as usize
+    })
+    .collect()
+}
+
+// one golden record: {n, uses_contra, allows_short, 0} u32 x 4, n base codes padded to a
+// multiple of 4 bytes, then the packed diagonal-major triangle of n(n+1)/2 f32
+// (pair (i, i+d) at d*n - d(d-1)/2 + i; -1.0 = absent from the reference's SparseProbMat)
+fn golden_record(out: &mut Vec<u8>, seq: &Seq, contra: bool, short: bool, f: &FoldScoreSets) {
+  let n = seq.len();
+  let probs = mccaskill_algo::<u16>(&seq[..], contra, short, f).0;
+  for x in [n as u32, contra as u32, short as u32, 0u32] {
+    out.extend_from_slice(&x.to_le_bytes());
+  }
+  out.extend(seq.iter().map(|&b| b as u8));
+  while out.len() % 4 != 0 {
+    out.push(0);
+  }
+  for d in 0..n {
+    for i in 0..n - d {
+      let p = probs.get(&(i as u16, (i + d) as u16)).copied().unwrap_or(-1.0);
+      out.extend_from_slice(&p.to_le_bytes());
+    }
+  }
+}
+
+fn main() {
+  let args: Vec<String> = std::env::args().collect();
+  if args.len() != 3 {
+    eprintln!("usage: dump_tables FASTA OUT_DIR");
+    std::process::exit(2);
+  }
+  let mut fold_score_sets = FoldScoreSets::new(0.);
+  fold_score_sets.transfer();
+  let block = params_block(&fold_score_sets);
+  let dir = Path::new(&args[2]);
+  let _ = create_dir(dir);
+  let mut tbl = File::create(dir.join("real_tables.tbl")).unwrap();
+  tbl.write_all(b"RNAMCTBL").unwrap();
+  tbl.write_all(&RNAMC_ABI_VERSION.to_le_bytes()).unwrap();
+  tbl.write_all(&(block.len() as u32).to_le_bytes()).unwrap();
+  tbl.write_all(&block).unwrap();
+
+  let mut seqs: Vec<Seq> = Reader::from_file(Path::new(&args[1]))
+    .unwrap()
+    .records()
+    .map(|r| bytes2seq(r.unwrap().seq()))
+    .collect();
+  seqs.push(synthetic_seq(200, 200));
+  seqs.push(synthetic_seq(400, 400));
+  let mut body = Vec::<u8>::new();
+  let mut n_records = 0u32;
+  for seq in seqs.iter() {
+    for (contra, short) in [(false, false), (true, false), (true, true)] {
+      golden_record(&mut body, seq, contra, short, &fold_score_sets);
+      n_records += 1;
+    }
+  }
+  let mut gld = File::create(dir.join("real_goldens.bin")).unwrap();
+  gld.write_all(b"RNAMCGLD").unwrap();
+  gld.write_all(&1u32.to_le_bytes()).unwrap();
+  gld.write_all(&n_records.to_le_bytes()).unwrap();
+  gld.write_all(&body).unwrap();
+  println!("wrote {} table bytes and {} golden records to {}", block.len(), n_records, dir.display());
+}

@@ -1,60 +1,33 @@
 // Drop-in body for the reference crate's `src/mccaskill_algo.rs` public entry point.
 //
-// NOT COMPILED IN THIS REPOSITORY (the build image has no Rust toolchain); kept
-// short so that a maintainer can check it by eye.  It keeps the signature of
+// NOT COMPILED IN THIS REPOSITORY (the build image has no Rust toolchain); kept short so
+// that a maintainer can check it by eye, and `tests/test_rust_shim_cpu.py` parses the
+// `extern "C"` block below against include/rnamc.h (every symbol, arity, integer width and
+// pointer-ness).  It keeps the signature of
 //     pub fn mccaskill_algo<T>(seq, uses_contra_model, allows_short_hairpins,
 //                              fold_score_sets) -> (SparseProbMat<T>, FoldScores<T>)
 // (reference: src/mccaskill_algo.rs:247-255) and replaces lines 256-279 by
-// pack -> FFI -> unpack.  `FoldSums`, `FoldScores`, `FoldScoreSets` and the four
-// stage functions stay as they are in the crate (their structs are not touched).
+// pack -> FFI -> unpack.  `FoldSums`, `FoldScores`, `FoldScoreSets` and the four stage
+// functions (`get_fold_sums{,_contra}`, `get_basepair_probs{,_contra}`) stay as they are in
+// the crate: they remain CPU Rust.
 //
-// Link: `cargo:rustc-link-lib=dylib=rnamc` + search path of librnamc.so (build.rs).
+// Semantics kept from the reference (src/mccaskill_algo.rs:247-280):
+//  * `fold_score_sets` is READ ON EVERY CALL: the device tables are re-uploaded whenever the
+//    contents of the argument differ from what the context holds (content hash, not object
+//    identity; nothing is cached per set);
+//  * `FoldScores<T>` is always filled (cargo feature "no-fold-scores" opts OUT for callers
+//    that only take `.0`, like the crate's own binaries);
+//  * errors panic, with librnamc's message.
+//
+// Link: build.rs (`cargo:rustc-link-lib=dylib=rnamc` + search path of librnamc.so).
 
 use std::os::raw::{c_char, c_int, c_void};
-use std::sync::OnceLock;
+use std::sync::Mutex;
 use utils::*;
 
 #[repr(C)]
 pub struct RnamcCtx {
   _private: [u8; 0],
-}
-
-extern "C" {
-  // include/rnamc.h
-  fn rnamc_params_sizeof() -> usize;
-  fn rnamc_params_load(path: *const c_char, out: *mut c_void) -> c_int;
-  fn rnamc_params_new(init_val: f32, out: *mut c_void) -> c_int;
-  fn rnamc_params_field(idx: u32, name: *mut *const c_char, off: *mut u64, cnt: *mut u64) -> c_int;
-  fn rnamc_params_set_special_hairpins(p: *mut c_void, n: u32, seqs: *const u8, lens: *const u8,
-    scores: *const f32) -> c_int;
-  fn rnamc_params_set_hairpin_limits(p: *mut c_void, min_len: u32, max_extrap: u32,
-    min_extrap: u32) -> c_int;
-  fn rnamc_ctx_create(params: *const c_void, device: c_int, ws: u64, out: *mut *mut RnamcCtx) -> c_int;
-  fn rnamc_bpp_len(n: u32) -> u64;
-  fn rnamc_bpp_batch(
-    ctx: *mut RnamcCtx,
-    n_seqs: u32,
-    bases: *const u8,
-    offsets: *const u64,
-    uses_contra_model: c_int,
-    allows_short_hairpins: c_int,
-    bpp: *mut f32,
-    out_offsets: *const u64,
-    log_partition: *mut f32,
-  ) -> c_int;
-  fn rnamc_fold_scores(
-    ctx: *mut RnamcCtx,
-    bases: *const u8,
-    n: u32,
-    uses_contra_model: c_int,
-    allows_short_hairpins: c_int,
-    hairpin_scores: *mut f32,
-    multibranch_close_scores: *mut f32,
-    accessible_scores: *mut f32,
-    twoloop_scores: *mut TwoloopScore,
-    twoloop_cap: u64,
-    twoloop_count: *mut u64,
-  ) -> c_int;
 }
 
 #[repr(C)]
@@ -67,28 +40,94 @@ pub struct TwoloopScore {
   score: f32,
 }
 
-struct Ctx(*mut RnamcCtx);
-unsafe impl Send for Ctx {}
-unsafe impl Sync for Ctx {} // calls on one ctx are serialised inside librnamc
-
-// One context per process: the tables are copied into a rnamc_params block by copy_tables.
-fn context(fold_score_sets: &FoldScoreSets) -> &'static Ctx {
-  static CTX: OnceLock<Ctx> = OnceLock::new();
-  CTX.get_or_init(|| unsafe {
-    let mut params = vec![0u8; rnamc_params_sizeof()];
-    assert_eq!(rnamc_params_new(0., params.as_mut_ptr() as *mut c_void), 0);
-    copy_tables(&mut params, fold_score_sets);
-    let mut ctx = std::ptr::null_mut();
-    assert_eq!(rnamc_ctx_create(params.as_ptr() as *const c_void, -1, 0, &mut ctx), 0);
-    Ctx(ctx)
-  })
+extern "C" {
+  // include/rnamc.h
+  fn rnamc_params_sizeof() -> usize;
+  fn rnamc_strerror(status: c_int) -> *const c_char;
+  fn rnamc_last_error() -> *const c_char;
+  fn rnamc_params_new(init_val: f32, out: *mut c_void) -> c_int;
+  fn rnamc_params_save(p: *const c_void, path: *const c_char) -> c_int;
+  fn rnamc_params_field(idx: u32, name: *mut *const c_char, byte_offset: *mut u64, count: *mut u64) -> c_int;
+  fn rnamc_params_set_special_hairpins(p: *mut c_void, n: u32, seqs: *const u8, lens: *const u8, scores: *const f32) -> c_int;
+  fn rnamc_params_set_hairpin_limits(p: *mut c_void, min_hairpin_len: u32, max_hairpin_len_extrapolation: u32, min_hairpin_len_extrapolation: u32) -> c_int;
+  fn rnamc_ctx_create(params: *const c_void, device: c_int, workspace_bytes: u64, out: *mut *mut RnamcCtx) -> c_int;
+  fn rnamc_ctx_set_params(ctx: *mut RnamcCtx, params: *const c_void) -> c_int;
+  fn rnamc_bpp_len(n: u32) -> u64;
+  fn rnamc_bpp_batch(ctx: *mut RnamcCtx, n_seqs: u32, bases: *const u8, offsets: *const u64, uses_contra_model: c_int, allows_short_hairpins: c_int, bpp: *mut f32, out_offsets: *const u64, log_partition: *mut f32) -> c_int;
+  fn rnamc_fold_scores(ctx: *mut RnamcCtx, bases: *const u8, n: u32, uses_contra_model: c_int, allows_short_hairpins: c_int, hairpin_scores: *mut f32, multibranch_close_scores: *mut f32, accessible_scores: *mut f32, twoloop_scores: *mut TwoloopScore, twoloop_cap: u64, twoloop_count: *mut u64) -> c_int;
 }
 
-// Fills the rnamc_params block: every f32 table by name (rnamc_params_field gives name, byte
+// panic with librnamc's own words (the reference panics on the same inputs:
+// src/utils.rs:570-572, src/mccaskill_algo.rs:526)
+fn check(status: c_int, what: &str) {
+  if status != 0 {
+    let (a, b) = unsafe {
+      (
+        std::ffi::CStr::from_ptr(rnamc_strerror(status)).to_string_lossy().into_owned(),
+        std::ffi::CStr::from_ptr(rnamc_last_error()).to_string_lossy().into_owned(),
+      )
+    };
+    panic!("{}: rnamc status {} ({}) {}", what, status, a, b);
+  }
+}
+
+// One device context per process (workspace and staging buffers are reused across calls);
+// `key` is the hash of the FoldScoreSets contents its tables were built from.
+struct State {
+  ctx: *mut RnamcCtx,
+  key: u64,
+}
+unsafe impl Send for State {}
+static STATE: Mutex<Option<State>> = Mutex::new(None);
+
+fn content_key(f: &FoldScoreSets) -> u64 {
+  // FNV-1a over the bytes of the set (f32 arrays and scalars only: no padding)
+  let bytes = unsafe {
+    std::slice::from_raw_parts(f as *const FoldScoreSets as *const u8, std::mem::size_of::<FoldScoreSets>())
+  };
+  let mut h = 0xcbf29ce484222325u64;
+  for &b in bytes {
+    h = (h ^ b as u64).wrapping_mul(0x100000001b3);
+  }
+  h
+}
+
+// Runs `f` with a context whose tables are `fold_score_sets`.  The lock is held across the
+// FFI call, so a caller on another thread with a different set cannot swap the tables under
+// it (calls on one context are serialised inside librnamc anyway).
+fn with_context<R>(fold_score_sets: &FoldScoreSets, f: impl FnOnce(*mut RnamcCtx) -> R) -> R {
+  let key = content_key(fold_score_sets);
+  let mut guard = STATE.lock().unwrap_or_else(|e| e.into_inner());
+  let stale = match guard.as_ref() {
+    Some(st) => st.key != key,
+    None => true,
+  };
+  if stale {
+    let params = build_params(fold_score_sets);
+    let p = params.as_ptr() as *const c_void;
+    match guard.as_mut() {
+      Some(st) => {
+        check(unsafe { rnamc_ctx_set_params(st.ctx, p) }, "rnamc_ctx_set_params");
+        st.key = key;
+      }
+      None => {
+        let mut ctx = std::ptr::null_mut();
+        check(unsafe { rnamc_ctx_create(p, -1, 0, &mut ctx) }, "rnamc_ctx_create");
+        *guard = Some(State { ctx, key });
+      }
+    }
+  }
+  f(guard.as_ref().unwrap().ctx)
+}
+
+// Fills a rnamc_params block: every f32 table by name (rnamc_params_field gives name, byte
 // offset and element count; multi-dimensional arrays are row-major like the Rust arrays),
 // then the special hairpins and the three hairpin length constants.  "turner.*" come from
-// rna_ss_params::compiled_scores_turner, "contra.*" from the FoldScoreSets the caller built.
-fn copy_tables(params: &mut [u8], f: &FoldScoreSets) {
+// rna_ss_params::compiled_scores_turner (what the reference's Turner branch reads directly,
+// src/utils.rs:166-411), "contra.*" from the FoldScoreSets the caller built.
+pub fn build_params(f: &FoldScoreSets) -> Vec<u8> {
+  let mut params = vec![0u8; unsafe { rnamc_params_sizeof() }];
+  check(unsafe { rnamc_params_new(0., params.as_mut_ptr() as *mut c_void) }, "rnamc_params_new");
   unsafe fn flat<A>(a: &A) -> &[f32] {
     std::slice::from_raw_parts(a as *const A as *const f32, std::mem::size_of::<A>() / 4)
   }
@@ -151,10 +190,17 @@ fn copy_tables(params: &mut [u8], f: &FoldScoreSets) {
         other => panic!("unknown rnamc_params field {}", other),
       }
     };
+    // a table whose shape differs from librnamc's compile-time limits (RNAMC_MAX_LOOP_LEN
+    // ...: recalled values of rna-ss-params constants) stops here, loudly
     assert_eq!(src.len() as u64, cnt, "shape of {}", name);
     let dst = &mut params[off as usize..off as usize + 4 * cnt as usize];
     dst.copy_from_slice(unsafe { std::slice::from_raw_parts(src.as_ptr() as *const u8, dst.len()) });
   }
+  // the limits librnamc was compiled with must be the crate's
+  assert_eq!(MAX_2LOOP_LEN, 30, "RNAMC_MAX_2LOOP_LEN");
+  assert_eq!(MAX_LOOP_LEN, 30, "RNAMC_MAX_LOOP_LEN");
+  assert_eq!(MIN_SPAN_HAIRPIN_CLOSE, 5, "RNAMC_MIN_SPAN_HAIRPIN_CLOSE");
+  assert_eq!(MAX_INTERIOR_EXPLICIT, 4, "RNAMC_MAX_INTERIOR_EXPLICIT");
   // HAIRPIN_SCORES_SPECIAL: (sequence, score) pairs (src/utils.rs:198-205)
   const W: usize = 16; // RNAMC_MAX_SPECIAL_HAIRPIN_LEN
   let n = HAIRPIN_SCORES_SPECIAL.len();
@@ -167,46 +213,33 @@ fn copy_tables(params: &mut [u8], f: &FoldScoreSets) {
     scores[x] = *score;
   }
   let p = params.as_mut_ptr() as *mut c_void;
-  unsafe {
-    assert_eq!(rnamc_params_set_special_hairpins(p, n as u32, seqs.as_ptr(), lens.as_ptr(), scores.as_ptr()), 0);
-    assert_eq!(rnamc_params_set_hairpin_limits(p, MIN_HAIRPIN_LEN as u32,
-      MAX_HAIRPIN_LEN_EXTRAPOLATION as u32, MIN_HAIRPIN_LEN_EXTRAPOLATION as u32), 0);
-  }
+  check(
+    unsafe { rnamc_params_set_special_hairpins(p, n as u32, seqs.as_ptr(), lens.as_ptr(), scores.as_ptr()) },
+    "rnamc_params_set_special_hairpins",
+  );
+  check(
+    unsafe {
+      rnamc_params_set_hairpin_limits(
+        p,
+        MIN_HAIRPIN_LEN as u32,
+        MAX_HAIRPIN_LEN_EXTRAPOLATION as u32,
+        MIN_HAIRPIN_LEN_EXTRAPOLATION as u32,
+      )
+    },
+    "rnamc_params_set_hairpin_limits",
+  );
+  params
 }
 
-pub fn mccaskill_algo<T>(
-  seq: SeqSlice,
-  uses_contra_model: bool,
-  allows_short_hairpins: bool,
-  fold_score_sets: &FoldScoreSets,
-) -> (SparseProbMat<T>, FoldScores<T>)
-where
-  T: HashIndex,
-{
-  let n = seq.len();
-  let bases: Vec<u8> = seq.iter().map(|&x| x as u8).collect();
-  let offsets = [0u64, n as u64];
-  let len = unsafe { rnamc_bpp_len(n as u32) } as usize;
-  let out_offsets = [0u64, len as u64];
-  let mut packed = vec![0f32; len.max(1)];
-  let mut log_partition = 0f32;
-  let status = unsafe {
-    rnamc_bpp_batch(
-      context(fold_score_sets).0,
-      1,
-      bases.as_ptr(),
-      offsets.as_ptr(),
-      uses_contra_model as c_int,
-      allows_short_hairpins as c_int,
-      packed.as_mut_ptr(),
-      out_offsets.as_ptr(),
-      &mut log_partition,
-    )
-  };
-  if status != 0 {
-    panic!(); // the reference panics on empty / invalid input (src/mccaskill_algo.rs:526)
-  }
-  // diagonal-major packed triangle -> SparseProbMat<T>; absent pairs hold -1.0
+// table file for hosts without the crate (Python mirror, tests): bindings/rust/dump_tables.rs
+pub fn save_params(f: &FoldScoreSets, path: &str) {
+  let params = build_params(f);
+  let c_path = std::ffi::CString::new(path).unwrap();
+  check(unsafe { rnamc_params_save(params.as_ptr() as *const c_void, c_path.as_ptr()) }, "rnamc_params_save");
+}
+
+// diagonal-major packed triangle -> SparseProbMat<T>; absent pairs hold -1.0
+fn unpack_probs<T: HashIndex>(packed: &[f32], n: usize) -> SparseProbMat<T> {
   let mut basepair_probs = SparseProbMat::<T>::default();
   let mut x = 0;
   for d in 0..n {
@@ -218,42 +251,113 @@ where
       }
     }
   }
-  // FoldScores<T>: no in-crate caller reads it (src/bin/*.rs take `.0`), so it is filled
-  // only when the crate is built with feature "fold-scores" (downstream crates that read it).
-  let fold_scores = if cfg!(feature = "fold-scores") {
-    get_fold_scores::<T>(&bases, uses_contra_model, allows_short_hairpins, fold_score_sets)
-  } else {
+  basepair_probs
+}
+
+// The whole FASTA in one device batch: what src/bin/mccaskill_algo.rs:58-93 and
+// src/bin/centroid_fold.rs:119-132 do with one pool task per record.  Called from that pool
+// instead, every per-sequence call would serialise on the context and run as a latency-bound
+// group of one.  Returns the `.0` of mccaskill_algo per record (the binaries discard `.1`).
+pub fn mccaskill_algo_batch<T>(
+  seqs: &[SeqSlice],
+  uses_contra_model: bool,
+  allows_short_hairpins: bool,
+  fold_score_sets: &FoldScoreSets,
+) -> Vec<SparseProbMat<T>>
+where
+  T: HashIndex,
+{
+  let mut bases = Vec::<u8>::new();
+  let (mut offsets, mut out_offsets) = (vec![0u64], vec![0u64]);
+  for seq in seqs {
+    bases.extend(seq.iter().map(|&x| x as u8));
+    offsets.push(bases.len() as u64);
+    out_offsets.push(out_offsets.last().unwrap() + unsafe { rnamc_bpp_len(seq.len() as u32) });
+  }
+  let mut packed = vec![0f32; (*out_offsets.last().unwrap() as usize).max(1)];
+  with_context(fold_score_sets, |ctx| {
+    check(
+      unsafe {
+        rnamc_bpp_batch(
+          ctx,
+          seqs.len() as u32,
+          bases.as_ptr(),
+          offsets.as_ptr(),
+          uses_contra_model as c_int,
+          allows_short_hairpins as c_int,
+          packed.as_mut_ptr(),
+          out_offsets.as_ptr(),
+          std::ptr::null_mut(),
+        )
+      },
+      "rnamc_bpp_batch",
+    )
+  });
+  seqs
+    .iter()
+    .enumerate()
+    .map(|(s, seq)| unpack_probs::<T>(&packed[out_offsets[s] as usize..out_offsets[s + 1] as usize], seq.len()))
+    .collect()
+}
+
+pub fn mccaskill_algo<T>(
+  seq: SeqSlice,
+  uses_contra_model: bool,
+  allows_short_hairpins: bool,
+  fold_score_sets: &FoldScoreSets,
+) -> (SparseProbMat<T>, FoldScores<T>)
+where
+  T: HashIndex,
+{
+  let basepair_probs = mccaskill_algo_batch::<T>(&[seq], uses_contra_model, allows_short_hairpins, fold_score_sets)
+    .pop()
+    .unwrap();
+  // FoldScores<T> is part of the reference's result and filled by default; callers that
+  // only take `.0` (src/bin/*.rs, tests/tests.rs, benches/benches.rs) may build the crate
+  // with feature "no-fold-scores" and get empty maps instead of ~n^2 * 186 hash inserts.
+  let fold_scores = if cfg!(feature = "no-fold-scores") {
     FoldScores::<T>::new()
+  } else {
+    get_fold_scores::<T>(seq, uses_contra_model, allows_short_hairpins, fold_score_sets)
   };
   (basepair_probs, fold_scores)
 }
 
 // The four maps of src/mccaskill_algo.rs:14-19 through rnamc_fold_scores: three packed
-// triangles (NaN = key absent) and the list of twoloop_scores inserts.
+// triangles (NaN = key absent) and the list of twoloop_scores inserts.  The first call
+// counts, the second fills; librnamc keeps the key set of the sequence between the two, so
+// the device sweep runs once.
 fn get_fold_scores<T: HashIndex>(
-  bases: &[u8],
+  seq: SeqSlice,
   uses_contra_model: bool,
   allows_short_hairpins: bool,
   fold_score_sets: &FoldScoreSets,
 ) -> FoldScores<T> {
-  let n = bases.len();
+  let n = seq.len();
+  let bases: Vec<u8> = seq.iter().map(|&x| x as u8).collect();
   let len = unsafe { rnamc_bpp_len(n as u32) } as usize;
   let (mut hp, mut mb, mut ac) = (vec![0f32; len], vec![0f32; len], vec![0f32; len]);
-  let ctx = context(fold_score_sets).0;
   let (c, s) = (uses_contra_model as c_int, allows_short_hairpins as c_int);
-  let mut count = 0u64;
   let p = bases.as_ptr();
-  unsafe {
-    let st = rnamc_fold_scores(ctx, p, n as u32, c, s, hp.as_mut_ptr(), mb.as_mut_ptr(),
-      ac.as_mut_ptr(), std::ptr::null_mut(), 0, &mut count);
-    assert_eq!(st, 0);
-  }
-  let mut tl = vec![TwoloopScore::default(); count as usize];
-  unsafe {
-    let st = rnamc_fold_scores(ctx, p, n as u32, c, s, std::ptr::null_mut(), std::ptr::null_mut(),
-      std::ptr::null_mut(), tl.as_mut_ptr(), count, &mut count);
-    assert_eq!(st, 0);
-  }
+  let tl = with_context(fold_score_sets, |ctx| {
+    let mut count = 0u64;
+    check(
+      unsafe {
+        rnamc_fold_scores(ctx, p, n as u32, c, s, hp.as_mut_ptr(), mb.as_mut_ptr(), ac.as_mut_ptr(),
+          std::ptr::null_mut(), 0, &mut count)
+      },
+      "rnamc_fold_scores (count)",
+    );
+    let mut tl = vec![TwoloopScore::default(); count as usize];
+    check(
+      unsafe {
+        rnamc_fold_scores(ctx, p, n as u32, c, s, std::ptr::null_mut(), std::ptr::null_mut(),
+          std::ptr::null_mut(), tl.as_mut_ptr(), count, &mut count)
+      },
+      "rnamc_fold_scores (fill)",
+    );
+    tl
+  });
   let mut out = FoldScores::<T>::new();
   let t = |x: usize| T::from_usize(x).unwrap();
   let mut x = 0;

@@ -210,6 +210,11 @@ typedef struct rnamc_ctx rnamc_ctx;
 int rnamc_ctx_create(const rnamc_params* params, int device, uint64_t workspace_bytes,
                      rnamc_ctx** out);
 void rnamc_ctx_destroy(rnamc_ctx* ctx);
+/* Replace the tables of a live context (waits for the context's earlier work).  The
+ * reference reads `&FoldScoreSets` on every call (src/mccaskill_algo.rs:247-280) and the
+ * set is trainable (src/utils.rs:91-119): a host mirror that caches a context calls this
+ * whenever the contents of the caller's set differ from the ones last uploaded. */
+int rnamc_ctx_set_params(rnamc_ctx* ctx, const rnamc_params* params);
 /* Tuning knobs (all optional): name in {"group_max_seqs","group_max_nt","group_ws_bytes",
  * "block_threads","fuse_inside","dual_outside","dual_min_cells","dual_max_diag",
  * "order_inside","order_outside","profile"}; returns RNAMC_ERR_INVALID_ARG for unknown names. */
@@ -280,7 +285,9 @@ int rnamc_debug_fetch(rnamc_ctx* ctx, uint32_t seq_idx, int which, float* out_nx
  *   twoloop_scores: up to twoloop_cap entries, closing pair (i,j) diagonal-major, then
  *     k ascending, l descending (the reference's visiting order); *twoloop_count gets the
  *     full count.  With twoloop_scores == NULL only the count is produced; a non-NULL
- *     buffer that is too small gives RNAMC_ERR_INVALID_ARG (count still set). */
+ *     buffer that is too small gives RNAMC_ERR_INVALID_ARG (count still set).
+ * The context keeps the key set of the last sequence it swept: the usual pair of calls
+ * (count, allocate, fill) on the same sequence and flags runs ONE device sweep. */
 typedef struct rnamc_twoloop_score {
   uint32_t i, j, k, l; /* (i,j) closes, (k,l) is enclosed */
   float score;

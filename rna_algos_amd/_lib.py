@@ -22,7 +22,7 @@ SYMBOLS = [
     "rnamc_fold_score_sets_transfer", "rnamc_params_new", "rnamc_params_synthetic",
     "rnamc_params_save", "rnamc_params_load", "rnamc_params_field",
     "rnamc_params_set_special_hairpins", "rnamc_params_set_hairpin_limits",
-    "rnamc_ctx_create", "rnamc_ctx_destroy", "rnamc_ctx_set",
+    "rnamc_ctx_create", "rnamc_ctx_destroy", "rnamc_ctx_set", "rnamc_ctx_set_params",
     "rnamc_bpp_batch", "rnamc_bpp_batch_device", "rnamc_ctx_last_stats",
     "rnamc_debug_fetch", "rnamc_fold_scores", "rnamc_centroid_fold",
 ]
@@ -88,6 +88,7 @@ def lib():
     L.rnamc_ctx_destroy.argtypes = [vp]
     L.rnamc_ctx_destroy.restype = None
     L.rnamc_ctx_set.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.rnamc_ctx_set_params.argtypes = [vp, vp]
     L.rnamc_bpp_batch.argtypes = [vp, C.c_uint32, vp, vp, C.c_int, C.c_int, vp, vp, vp]
     L.rnamc_bpp_batch_device.argtypes = [vp, C.c_uint32, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.rnamc_ctx_last_stats.argtypes = [vp, C.POINTER(BatchStats)]

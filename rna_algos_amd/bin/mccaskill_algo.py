@@ -12,7 +12,7 @@ import sys
 
 import numpy as np
 
-from ..utils import FoldScoreSets, read_fasta
+from ..utils import FoldScoreSets, NoTablesError, read_fasta, set_default_tables
 from ..mccaskill_algo import mccaskill_algo_batch
 
 HEADER = ("# Format = >{RNA sequence id} {line break} {basepairing left nucleotide}, "
@@ -47,10 +47,22 @@ def main(argv=None):
     ap.add_argument("-o", "--output_file_path", required=True)
     ap.add_argument("-t", "--num_threads", type=int, default=0)
     ap.add_argument("-c", "--uses_contra_model", action="store_true")
+    ap.add_argument("--synthetic-tables", type=int, default=None, metavar="SEED",
+                    help="NOT the reference's parameters: seeded synthetic tables (testing only). "
+                         "Without it $RNAMC_TABLES must name a table file dumped from the "
+                         "rna-ss-params crate")
     args = ap.parse_args(argv)
+    if args.synthetic_tables is not None:
+        set_default_tables(FoldScoreSets.synthetic(args.synthetic_tables))
+        print(f"warning: SYNTHETIC scoring tables (seed {args.synthetic_tables}): the output is "
+              "not comparable with the reference's", file=sys.stderr)
     recs = read_fasta(args.input_file_path)
     fold_score_sets = FoldScoreSets.new(0.0)
-    fold_score_sets.transfer()
+    try:
+        fold_score_sets.transfer()
+    except NoTablesError as e:
+        print(f"error: {e}", file=sys.stderr)
+        return 2
     mats, _ = mccaskill_algo_batch([s for _, s in recs], args.uses_contra_model, False,
                                    fold_score_sets)
     buf = [HEADER]

@@ -10,7 +10,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <atomic>
 #include <mutex>
@@ -45,10 +47,17 @@ struct rnamc_ctx {
   SeqDesc* d_seqs = nullptr;
   uint64_t seqs_cap = 0;
   // host-buffer entry: device staging of bases / result / log partition (grow-only)
+  // The result is staged per lock-step GROUP in two alternating device buffers: group g's
+  // D2H (copy stream, pinned bounce chunks, a host thread) runs while group g+1 sweeps.
   uint8_t* st_bases = nullptr;
-  float* st_out = nullptr;
+  float* st_out[2] = {nullptr, nullptr};
   float* st_logz = nullptr;
-  uint64_t st_bases_cap = 0, st_out_cap = 0, st_logz_cap = 0;
+  uint64_t st_bases_cap = 0, st_out_cap[2] = {0, 0}, st_logz_cap = 0;
+  hipStream_t copy_stream = nullptr;
+  float* pinned[2] = {nullptr, nullptr};  // bounce chunks (hipHostMalloc)
+  hipEvent_t pinned_ev[2] = {nullptr, nullptr};
+  hipEvent_t group_done[2] = {nullptr, nullptr};
+  std::vector<uint64_t> group_out_floats;  // per group, when the output is staged group-local
   hipStream_t own_stream = nullptr;
   hipStream_t aux_stream = nullptr;           // pair tail of large outside launches
   std::vector<hipEvent_t> ev_a, ev_b;         // per-diagonal completion, ring of 16
@@ -67,7 +76,9 @@ struct rnamc_ctx {
   int64_t dual_max_diag = 1 << 30;  // ... while the diagonal has at most this many cells
   bool inside_only = false;  // set by rnamc_fold_scores around its own batch call
   int64_t fuse_inside = 1;  // Turner: fold two diagonals per launch where launches are large
-  int64_t debug_roles = 15;  // timing experiments only: bit0 folds, 1 pair block, 2 mb, 3 pair probs
+  // role mask of timing experiments (bit0 folds, 1 pair block, 2 mb, 3 pair probs); settable
+  // only in builds with -DRNAMC_DEBUG_KNOBS (make DEBUG_KNOBS=1), constant 15 otherwise
+  int64_t debug_roles = 15;
   // bookkeeping of the last call
   rnamc_batch_stats stats{};
   std::vector<SeqDesc> descs;       // all groups, group-major
@@ -75,6 +86,11 @@ struct rnamc_ctx {
   std::vector<hipEvent_t> events;
   std::vector<hipEvent_t> kev;        // per-launch event pairs of the outside kernels (profiling)
   std::vector<uint8_t> kev_class;     // 0 main, 1 tail, 2 small; one per pair
+  // rnamc_fold_scores: sums_close key set of the last sequence it swept, so that the usual
+  // "count, allocate, fill" pair of calls runs the device sweep once
+  std::vector<uint8_t> fs_bases;
+  std::vector<float> fs_qb;
+  int fs_contra = -1, fs_short = -1;
 };
 
 namespace {
@@ -139,14 +155,23 @@ int ensure_ws(rnamc_ctx* c, uint64_t floats) {
   return RNAMC_OK;
 }
 
+// Per-group hooks of the host-buffer entry: where group g's result goes, and what happens
+// once its work is enqueued.  With hooks the output offsets are group-local (packed in group
+// order), without them the caller's out_offsets address one device buffer.
+struct GroupHooks {
+  std::function<int(size_t g, float** out_base)> before;
+  std::function<int(size_t g, uint32_t first_desc, uint32_t n_desc)> after;
+};
+
 // Core: everything device-resident, work enqueued on `st`.
 int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint64_t* offsets,
               bool contra, bool allows_short, float* d_out, const uint64_t* out_offsets,
-              float* d_logz, hipStream_t st) {
+              float* d_logz, hipStream_t st, const GroupHooks* hooks = nullptr) {
   c->stats = rnamc_batch_stats{};
   c->kev_class.clear();
   c->descs.clear();
   c->group_begin.clear();
+  c->group_out_floats.clear();
   if (n_seqs == 0) return RNAMC_OK;
   uint32_t max_n = 0;
   for (uint32_t s = 0; s < n_seqs; s++) {
@@ -169,7 +194,7 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
   const uint64_t ws_cap_floats = static_cast<uint64_t>(std::max<int64_t>(c->group_ws_bytes, 1)) / 4;
   uint64_t max_group_floats = 0;
   {
-    uint64_t cur = 0, cur_nt = 0;
+    uint64_t cur = 0, cur_nt = 0, cur_out = 0;
     uint32_t cnt = 0;
     for (uint32_t x = 0; x < n_seqs; x++) {
       const uint32_t s = order[x];
@@ -187,8 +212,10 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
                       cur_nt + n > static_cast<uint64_t>(c->group_max_nt) ||
                       cur + need > ws_cap_floats)) {
         max_group_floats = std::max(max_group_floats, cur);
+        c->group_out_floats.push_back(cur_out);
         cur = 0;
         cur_nt = 0;
+        cur_out = 0;
         cnt = 0;
       }
       if (cnt == 0) c->group_begin.push_back(static_cast<uint32_t>(c->descs.size()));
@@ -197,7 +224,7 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
       sd.tri_pad = static_cast<uint32_t>(tri_pad_of(n));
       sd.seq_off = offsets[s];
       sd.ws_off = cur;
-      sd.out_off = out_offsets[s];
+      sd.out_off = hooks ? cur_out : out_offsets[s];
       sd.batch_idx = s;
       sd.pk_words = static_cast<uint32_t>(pk_words);
       sd.pk_off = cur + tri_pad_of(n) * M_COUNT;
@@ -207,9 +234,11 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
       c->descs.push_back(sd);
       cur += need;
       cur_nt += n;
+      cur_out += rnamc_bpp_len(n);
       cnt++;
     }
     max_group_floats = std::max(max_group_floats, cur);
+    c->group_out_floats.push_back(cur_out);
     c->group_begin.push_back(static_cast<uint32_t>(c->descs.size()));
   }
   rc = ensure_ws(c, max_group_floats);
@@ -251,6 +280,10 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
     b.bases = d_bases;
     b.workspace = c->d_ws;
     b.out = d_out;
+    if (hooks) {
+      rc = hooks->before(g, &b.out);
+      if (rc) return rc;
+    }
     b.log_partition = d_logz;
     b.params = c->d_params;
     b.hp_init = c->d_hp_init;
@@ -403,6 +436,10 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
     c->stats.launches_other++;
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 3], st));
     HIPCHK(hipGetLastError());
+    if (hooks) {
+      rc = hooks->after(g, gb, nseq);
+      if (rc) return rc;
+    }
   }
   c->stats.n_groups = n_groups;
   c->stats.workspace_bytes = c->ws_floats * sizeof(float);
@@ -487,12 +524,8 @@ void fold_scores_host(const Model& M, bool contra, bool allows_short, const uint
 
 }  // namespace
 
-extern "C" {
-
-int rnamc_ctx_create(const rnamc_params* params, int device, uint64_t workspace_bytes,
-                     rnamc_ctx** out) {
-  if (!params || !out) return RNAMC_ERR_INVALID_ARG;
-  *out = nullptr;
+namespace {
+int validate_params(const rnamc_params* params) {
   if (params->abi_version != RNAMC_ABI_VERSION || params->struct_bytes != sizeof(rnamc_params)) {
     set_last_error("rnamc_params header does not match this library's ABI");
     return RNAMC_ERR_INVALID_ARG;
@@ -505,6 +538,17 @@ int rnamc_ctx_create(const rnamc_params* params, int device, uint64_t workspace_
     set_last_error("Turner hairpin limits out of range");
     return RNAMC_ERR_INVALID_ARG;
   }
+  return RNAMC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int rnamc_ctx_create(const rnamc_params* params, int device, uint64_t workspace_bytes,
+                     rnamc_ctx** out) {
+  if (!params || !out) return RNAMC_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (int rc = validate_params(params)) return rc;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
     set_last_error("no HIP device visible: librnamc has no CPU fallback");
@@ -565,7 +609,13 @@ void rnamc_ctx_destroy(rnamc_ctx* c) {
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->st_bases) (void)hipFree(c->st_bases);
-    if (c->st_out) (void)hipFree(c->st_out);
+    for (int k = 0; k < 2; k++) {
+      if (c->st_out[k]) (void)hipFree(c->st_out[k]);
+      if (c->pinned[k]) (void)hipHostFree(c->pinned[k]);
+      if (c->pinned_ev[k]) (void)hipEventDestroy(c->pinned_ev[k]);
+      if (c->group_done[k]) (void)hipEventDestroy(c->group_done[k]);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->st_logz) (void)hipFree(c->st_logz);
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->d_hp_init) (void)hipFree(c->d_hp_init);
@@ -573,6 +623,22 @@ void rnamc_ctx_destroy(rnamc_ctx* c) {
     if (c->d_seqs) (void)hipFree(c->d_seqs);
   }
   delete c;
+}
+
+int rnamc_ctx_set_params(rnamc_ctx* c, const rnamc_params* params) {
+  if (!c || !params) return RNAMC_ERR_INVALID_ARG;
+  if (int rc = validate_params(params)) return rc;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  DeviceGuard guard(c->device);
+  if (!guard.ok) return RNAMC_ERR_NO_DEVICE;
+  // work of earlier calls may still read the old tables
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(c->d_params, params, sizeof(rnamc_params), hipMemcpyHostToDevice));
+  c->host_params = *params;
+  c->hp_init_len = 0;  // the hairpin extrapolation table is derived from the Turner block
+  c->fs_contra = c->fs_short = -1;
+  c->fs_bases.clear();
+  return RNAMC_OK;
 }
 
 int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
@@ -602,8 +668,10 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     c->dual_min_cells = static_cast<uint64_t>(value);
   } else if (k == "fuse_inside") {
     c->fuse_inside = value;
+#ifdef RNAMC_DEBUG_KNOBS  // result-changing: timing experiments only, never in a release build
   } else if (k == "debug_roles") {
     c->debug_roles = value;
+#endif
   } else {
     return RNAMC_ERR_INVALID_ARG;
   }
@@ -639,36 +707,22 @@ int rnamc_bpp_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* bases, const u
   std::lock_guard<std::recursive_mutex> lock(c->mu);
   DeviceGuard guard(c->device);
   if (!guard.ok) return RNAMC_ERR_NO_DEVICE;
-  // device-side packing: bases as given; bpp triangles packed back to back
   const uint64_t base_lo = offsets[0], base_hi = offsets[n_seqs];
-  std::vector<uint64_t> doff(n_seqs + 1), dout(n_seqs + 1);
-  dout[0] = 0;
-  for (uint32_t s = 0; s < n_seqs; s++) {
-    doff[s] = offsets[s] - base_lo;
-    dout[s + 1] = dout[s] + rnamc_bpp_len(static_cast<uint32_t>(offsets[s + 1] - offsets[s]));
-  }
-  doff[n_seqs] = base_hi - base_lo;
-  // staging buffers live in the context and only grow (a caller that folds one record
-  // after another, like the reference's binaries, would otherwise pay a hipMalloc/hipFree
-  // triple per call)
-  int rc = RNAMC_OK;
-#define HIPCHK_CLEAN(expr)                                                 \
-  do {                                                                     \
-    hipError_t _e = (expr);                                                \
-    if (_e != hipSuccess) {                                                \
-      set_last_error(std::string(#expr) + ": " + hipGetErrorString(_e));   \
-      return (_e == hipErrorOutOfMemory) ? RNAMC_ERR_OOM : RNAMC_ERR_HIP;  \
-    }                                                                      \
-  } while (0)
+  std::vector<uint64_t> doff(n_seqs + 1);
+  for (uint32_t s = 0; s <= n_seqs; s++) doff[s] = offsets[s] - base_lo;
+  // Staging buffers live in the context and only grow (a caller that folds one record after
+  // another, like the reference's binaries, would otherwise pay hipMalloc/hipFree per call).
+  // The result is never staged whole: group g's triangles sit in st_out[g & 1] while a host
+  // thread drains them (copy stream -> pinned bounce chunks -> the caller's buffers) and
+  // group g+1 sweeps into the other buffer.
   auto grow = [&](void** p, uint64_t* cap, uint64_t need) -> hipError_t {
     if (*cap >= need && *p) return hipSuccess;
     if (*p) {
-      (void)hipStreamSynchronize(c->own_stream);
       (void)hipFree(*p);
       *p = nullptr;
       *cap = 0;
     }
-    const uint64_t want = std::max<uint64_t>(need + need / 4, 4096);
+    const uint64_t want = std::max<uint64_t>(need + need / 8, 4096);
     hipError_t e = hipMalloc(p, want);
     if (e != hipSuccess) {  // the headroom is optional
       e = hipMalloc(p, std::max<uint64_t>(need, 1));
@@ -678,37 +732,147 @@ int rnamc_bpp_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* bases, const u
     *cap = want;
     return hipSuccess;
   };
-  HIPCHK_CLEAN(grow(reinterpret_cast<void**>(&c->st_bases), &c->st_bases_cap, base_hi - base_lo));
-  HIPCHK_CLEAN(grow(reinterpret_cast<void**>(&c->st_out), &c->st_out_cap,
-                    dout[n_seqs] * sizeof(float)));
-  HIPCHK_CLEAN(grow(reinterpret_cast<void**>(&c->st_logz), &c->st_logz_cap,
-                    static_cast<uint64_t>(n_seqs) * sizeof(float)));
-  uint8_t* d_bases = c->st_bases;
-  float* d_out = c->st_out;
-  float* d_logz = c->st_logz;
-  HIPCHK_CLEAN(hipMemcpyAsync(d_bases, bases + base_lo, base_hi - base_lo, hipMemcpyHostToDevice,
-                              c->own_stream));
-  rc = run_batch(c, n_seqs, d_bases, doff.data(), uses_contra_model != 0,
-                 allows_short_hairpins != 0, d_out, dout.data(), d_logz, c->own_stream);
+  constexpr uint64_t kChunkFloats = 16ull << 20;  // 64 MB bounce chunks
+  if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  for (int k = 0; k < 2; k++) {
+    if (!c->pinned[k]) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->pinned[k]), kChunkFloats * sizeof(float), hipHostMallocDefault));
+    if (!c->pinned_ev[k]) HIPCHK(hipEventCreateWithFlags(&c->pinned_ev[k], hipEventDisableTiming));
+    if (!c->group_done[k]) HIPCHK(hipEventCreateWithFlags(&c->group_done[k], hipEventDisableTiming));
+  }
+  HIPCHK(hipStreamSynchronize(c->own_stream));
+  HIPCHK(grow(reinterpret_cast<void**>(&c->st_bases), &c->st_bases_cap, base_hi - base_lo));
+  HIPCHK(grow(reinterpret_cast<void**>(&c->st_logz), &c->st_logz_cap,
+              static_cast<uint64_t>(n_seqs) * sizeof(float)));
+  HIPCHK(hipMemcpyAsync(c->st_bases, bases + base_lo, base_hi - base_lo, hipMemcpyHostToDevice,
+                        c->own_stream));
+
+  // drain thread: one job per group, in order
+  struct Job {
+    size_t g;
+    uint32_t first, count;
+  };
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<Job> jobs;
+  size_t jobs_taken = 0, drained = 0;  // groups handed over / fully copied out
+  bool stop = false;
+  int drain_err = RNAMC_OK;
+  std::string drain_msg;
+  const int device = c->device;
+  auto drain = [&]() {
+    (void)hipSetDevice(device);
+    for (;;) {
+      Job job;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || jobs_taken < jobs.size(); });
+        if (jobs_taken >= jobs.size()) return;  // stop and nothing left
+        job = jobs[jobs_taken++];
+      }
+      const int k = static_cast<int>(job.g & 1);
+      hipError_t e = hipEventSynchronize(c->group_done[k]);
+      const uint64_t total = c->group_out_floats[job.g];
+      const float* src = c->st_out[k];
+      const uint64_t nchunks = (total + kChunkFloats - 1) / kChunkFloats;
+      auto issue = [&](uint64_t ch) {
+        const uint64_t lo = ch * kChunkFloats, len = std::min(kChunkFloats, total - lo);
+        hipError_t e2 = hipMemcpyAsync(c->pinned[ch & 1], src + lo, len * sizeof(float),
+                                       hipMemcpyDeviceToHost, c->copy_stream);
+        if (e2 == hipSuccess) e2 = hipEventRecord(c->pinned_ev[ch & 1], c->copy_stream);
+        return e2;
+      };
+      uint32_t cur = job.first;  // descriptor whose triangle holds the next float to place
+      if (e == hipSuccess && nchunks) e = issue(0);
+      for (uint64_t ch = 0; ch < nchunks && e == hipSuccess; ch++) {
+        if (ch + 1 < nchunks) e = issue(ch + 1);
+        if (e == hipSuccess) e = hipEventSynchronize(c->pinned_ev[ch & 1]);
+        if (e != hipSuccess) break;
+        // scatter [lo, hi) of the group's staging buffer to the caller's triangles
+        const uint64_t lo = ch * kChunkFloats, hi = std::min(total, lo + kChunkFloats);
+        uint64_t pos = lo;
+        while (pos < hi) {
+          const SeqDesc& sd = c->descs[cur];
+          const uint64_t s_lo = sd.out_off, s_hi = sd.out_off + rnamc_bpp_len(sd.n);
+          if (pos >= s_hi) {
+            cur++;
+            continue;
+          }
+          const uint64_t upto = std::min(hi, s_hi);
+          std::memcpy(bpp + out_offsets[sd.batch_idx] + (pos - s_lo), c->pinned[ch & 1] + (pos - lo),
+                      (upto - pos) * sizeof(float));
+          pos = upto;
+        }
+      }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (e != hipSuccess && drain_err == RNAMC_OK) {
+          drain_err = RNAMC_ERR_HIP;
+          drain_msg = std::string("result drain: ") + hipGetErrorString(e);
+        }
+        drained++;
+      }
+      cv.notify_all();
+    }
+  };
+  std::thread drainer(drain);
+  GroupHooks hooks;
+  hooks.before = [&](size_t g, float** out_base) -> int {
+    const int k = static_cast<int>(g & 1);
+    {
+      // buffer k was last used by group g-2: wait until it is copied out
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return g < 2 || drained + 2 > g; });
+      if (drain_err) return drain_err;
+    }
+    const uint64_t need = std::max<uint64_t>(c->group_out_floats[g], 1) * sizeof(float);
+    if (c->st_out_cap[k] < need) {
+      // nothing on the device still writes to or reads from this buffer, but a free
+      // synchronises the device: rare (buffers only grow)
+      hipError_t e = grow(reinterpret_cast<void**>(&c->st_out[k]), &c->st_out_cap[k], need);
+      if (e != hipSuccess) {
+        set_last_error(std::string("result staging buffer: ") + hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? RNAMC_ERR_OOM : RNAMC_ERR_HIP;
+      }
+    }
+    *out_base = c->st_out[k];
+    return RNAMC_OK;
+  };
+  hooks.after = [&](size_t g, uint32_t first, uint32_t count) -> int {
+    HIPCHK(hipEventRecord(c->group_done[g & 1], c->own_stream));
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      jobs.push_back(Job{g, first, count});
+    }
+    cv.notify_all();
+    return RNAMC_OK;
+  };
+  int rc = run_batch(c, n_seqs, c->st_bases, doff.data(), uses_contra_model != 0,
+                     allows_short_hairpins != 0, nullptr, out_offsets, c->st_logz, c->own_stream,
+                     &hooks);
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    stop = true;
+  }
+  cv.notify_all();
+  drainer.join();
+  if (rc == RNAMC_OK && drain_err) {
+    set_last_error(drain_msg);
+    rc = drain_err;
+  }
   if (rc) {
     (void)hipStreamSynchronize(c->own_stream);
     return rc;
   }
-  for (uint32_t s = 0; s < n_seqs; s++) {
-    HIPCHK_CLEAN(hipMemcpyAsync(bpp + out_offsets[s], d_out + dout[s],
-                                (dout[s + 1] - dout[s]) * sizeof(float), hipMemcpyDeviceToHost,
-                                c->own_stream));
-  }
   if (log_partition)
-    HIPCHK_CLEAN(hipMemcpyAsync(log_partition, d_logz, n_seqs * sizeof(float),
-                                hipMemcpyDeviceToHost, c->own_stream));
-  HIPCHK_CLEAN(hipStreamSynchronize(c->own_stream));
-#undef HIPCHK_CLEAN
-  if (c->st_out_cap > (1ull << 30)) {  // a big one-off batch should not keep its result staged
-    (void)hipFree(c->st_out);
-    c->st_out = nullptr;
-    c->st_out_cap = 0;
-  }
+    HIPCHK(hipMemcpyAsync(log_partition, c->st_logz, n_seqs * sizeof(float), hipMemcpyDeviceToHost,
+                          c->own_stream));
+  HIPCHK(hipStreamSynchronize(c->own_stream));
+  for (int k = 0; k < 2; k++)
+    if (c->st_out_cap[k] > (2ull << 30)) {  // a big one-off batch should not keep its result staged
+      (void)hipFree(c->st_out[k]);
+      c->st_out[k] = nullptr;
+      c->st_out_cap[k] = 0;
+    }
   return RNAMC_OK;
 }
 
@@ -763,22 +927,33 @@ int rnamc_fold_scores(rnamc_ctx* c, const uint8_t* bases, uint32_t n, int uses_c
   if (!c || !bases) return RNAMC_ERR_INVALID_ARG;
   if (n == 0) return RNAMC_ERR_EMPTY_SEQ;
   std::lock_guard<std::recursive_mutex> lock(c->mu);
-  // the device sweep of this one sequence leaves sums_close in the workspace
-  const uint64_t offsets[2] = {0, n}, out_offsets[2] = {0, 0};
   const uint64_t tri_len = rnamc_bpp_len(n);
-  std::vector<float> bpp(tri_len);
-  c->inside_only = true;
-  int rc = rnamc_bpp_batch(c, 1, bases, offsets, uses_contra_model, allows_short_hairpins,
-                           bpp.data(), out_offsets, nullptr);
-  c->inside_only = false;
-  if (rc) return rc;
-  DeviceGuard guard(c->device);
-  if (!guard.ok) return RNAMC_ERR_NO_DEVICE;
-  const SeqDesc& sd = c->descs.back();
-  std::vector<float>& qb = bpp;  // sums_close, packed diagonal-major like the result
-  HIPCHK(hipMemcpy(qb.data(), c->d_ws + sd.ws_off + static_cast<uint64_t>(M_QB) * sd.tri_pad,
-                   tri_len * sizeof(float), hipMemcpyDeviceToHost));
   const bool contra = uses_contra_model != 0, shorthp = allows_short_hairpins != 0;
+  const bool cached = c->fs_contra == (contra ? 1 : 0) && c->fs_short == (shorthp ? 1 : 0) &&
+                      c->fs_bases.size() == n && std::memcmp(c->fs_bases.data(), bases, n) == 0 &&
+                      c->fs_qb.size() == tri_len;
+  if (!cached) {
+    // the device sweep of this one sequence leaves sums_close in the workspace
+    const uint64_t offsets[2] = {0, n}, out_offsets[2] = {0, 0};
+    c->fs_contra = c->fs_short = -1;
+    c->fs_qb.assign(tri_len, 0.f);
+    c->inside_only = true;
+    int rc = rnamc_bpp_batch(c, 1, bases, offsets, uses_contra_model, allows_short_hairpins,
+                             c->fs_qb.data(), out_offsets, nullptr);
+    c->inside_only = false;
+    if (rc) return rc;
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return RNAMC_ERR_NO_DEVICE;
+    const SeqDesc& sd = c->descs.back();
+    // sums_close, packed diagonal-major like the result
+    HIPCHK(hipMemcpy(c->fs_qb.data(),
+                     c->d_ws + sd.ws_off + static_cast<uint64_t>(M_QB) * sd.tri_pad,
+                     tri_len * sizeof(float), hipMemcpyDeviceToHost));
+    c->fs_bases.assign(bases, bases + n);
+    c->fs_contra = contra ? 1 : 0;
+    c->fs_short = shorthp ? 1 : 0;
+  }
+  const std::vector<float>& qb = c->fs_qb;
   std::vector<uint64_t> count(n, 0), begin(n + 1, 0);
   const Turner MT{c->host_params.turner, c->h_hp_init.data()};
   const Contra MC{c->host_params.contra};

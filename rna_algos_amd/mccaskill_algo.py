@@ -111,9 +111,16 @@ class Context:
 
     def __init__(self, fold_score_sets, device=-1, workspace_bytes=0):
         self._h = C.c_void_p()
-        self._fss = fold_score_sets
+        self._key = fold_score_sets.content_key()
         _lib.check(_lib.lib().rnamc_ctx_create(fold_score_sets.ptr, device, workspace_bytes,
                                                C.byref(self._h)))
+
+    def sync_params(self, fold_score_sets):
+        """Upload the tables again if their contents differ from the ones on the device."""
+        key = fold_score_sets.content_key()
+        if key != self._key:
+            _lib.check(_lib.lib().rnamc_ctx_set_params(self._h, fold_score_sets.ptr))
+            self._key = key
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -152,6 +159,19 @@ class Context:
                 for s in range(len(seqs))]
         return mats, logz
 
+    def bpp_batch_into(self, bases, offsets, uses_contra_model, allows_short_hairpins, bpp,
+                       out_offsets, log_partition=None):
+        """rnamc_bpp_batch on caller-owned host buffers (numpy arrays): H2D + kernels + D2H."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        out_offsets = np.ascontiguousarray(out_offsets, dtype=np.uint64)
+        assert bpp.dtype == np.float32 and bpp.flags.c_contiguous
+        _lib.check(_lib.lib().rnamc_bpp_batch(
+            self._h, len(offsets) - 1, bases.ctypes.data, offsets.ctypes.data,
+            int(bool(uses_contra_model)), int(bool(allows_short_hairpins)), bpp.ctypes.data,
+            out_offsets.ctypes.data,
+            log_partition.ctypes.data if log_partition is not None else None))
+
     def bpp_batch_device(self, n_seqs, d_bases_ptr, offsets, uses_contra_model,
                          allows_short_hairpins, d_bpp_ptr, out_offsets, d_logz_ptr, stream_ptr):
         """Everything already in HBM; enqueues on `stream_ptr` and returns."""
@@ -185,26 +205,31 @@ class Context:
         return out
 
 
-_ctx_cache = {}
-_ctx_lock = threading.Lock()
+# ONE device context per process for the module-level functions (workspace and staging
+# buffers are reused across calls).  The reference reads `&FoldScoreSets` on every call, and
+# the set is mutable: the tables are re-uploaded whenever their CONTENT differs from what the
+# context holds — never keyed by object identity, nothing is kept alive per set.
+_ctx = None
+_ctx_lock = threading.RLock()
 
 
 def _context_for(fold_score_sets):
-    key = id(fold_score_sets)
+    global _ctx
     with _ctx_lock:
-        ctx = _ctx_cache.get(key)
-        if ctx is None or ctx._fss is not fold_score_sets:
-            ctx = Context(fold_score_sets)
-            _ctx_cache[key] = ctx
-        return ctx
+        if _ctx is None:
+            _ctx = Context(fold_score_sets)
+        else:
+            _ctx.sync_params(fold_score_sets)
+        return _ctx
 
 
 def mccaskill_algo_packed(seq, uses_contra_model, allows_short_hairpins, fold_score_sets):
     seq = np.asarray(seq, dtype=np.uint8)
     if seq.shape[0] > MAX_SEQ_LEN:
         raise _lib.RnamcError(_lib.ERR_SEQ_TOO_LONG)
-    mats, logz = _context_for(fold_score_sets).bpp_batch([seq], uses_contra_model,
-                                                         allows_short_hairpins)
+    with _ctx_lock:  # tables of the shared context stay the caller's until the call returns
+        mats, logz = _context_for(fold_score_sets).bpp_batch([seq], uses_contra_model,
+                                                             allows_short_hairpins)
     return mats[0], float(logz[0])
 
 
@@ -212,12 +237,18 @@ def mccaskill_algo(seq, uses_contra_model, allows_short_hairpins, fold_score_set
     """(SparseProbMat, FoldScores) like the reference (src/mccaskill_algo.rs:247-280)."""
     mat, _ = mccaskill_algo_packed(seq, uses_contra_model, allows_short_hairpins, fold_score_sets)
     seq = np.array(seq, dtype=np.uint8)
-    ctx = _context_for(fold_score_sets)
-    return mat.sparse(), FoldScores(
-        lambda: ctx.fold_scores_packed(seq, uses_contra_model, allows_short_hairpins))
+    # the maps are filled on first access, with the tables as they were at call time
+    frozen = FoldScoreSets(_buf=fold_score_sets._buf.copy())
+
+    def materialise():
+        with _ctx_lock:
+            return _context_for(frozen).fold_scores_packed(seq, uses_contra_model,
+                                                           allows_short_hairpins)
+    return mat.sparse(), FoldScores(materialise)
 
 
 def mccaskill_algo_batch(seqs, uses_contra_model, allows_short_hairpins, fold_score_sets):
     """Whole FASTA at once (what src/bin/mccaskill_algo.rs:64-93 does on a thread pool)."""
-    return _context_for(fold_score_sets).bpp_batch(list(seqs), uses_contra_model,
-                                                   allows_short_hairpins)
+    with _ctx_lock:
+        return _context_for(fold_score_sets).bpp_batch(list(seqs), uses_contra_model,
+                                                       allows_short_hairpins)

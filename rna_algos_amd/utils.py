@@ -117,8 +117,9 @@ class FoldScoreSets:
 
     def transfer(self, source=None):
         """Copy the compiled tables (of `source`, default: the table set named by
-        $RNAMC_TABLES or synthetic seed 0) the way the reference's transfer() copies
-        the crate constants; Turner constants are taken over as they are."""
+        $RNAMC_TABLES / set_default_tables(); raises NoTablesError when neither is given) the
+        way the reference's transfer() copies the crate constants; Turner constants are taken
+        over as they are."""
         src = source if source is not None else default_tables()
         off, _ = self._fields["contra.hairpin_scores_len"]
         # Turner block and header come over wholesale; the contra block goes through
@@ -133,6 +134,18 @@ class FoldScoreSets:
     @property
     def ptr(self):
         return self._buf.ctypes.data
+
+    def content_key(self):
+        """Digest of the whole parameter block: host mirrors re-upload the tables of a
+        cached device context when this changes (the set is mutable, the reference reads it
+        on every call)."""
+        import hashlib
+        return hashlib.blake2b(self._buf.tobytes(), digest_size=16).digest()
+
+    @property
+    def is_synthetic(self):
+        """table_id of the header: rnamc_params_synthetic tags it "SYNT" ^ seed."""
+        return (int(self._buf[8:16].view(np.uint64)[0]) >> 32) == 0x53594E54
 
     def field(self, qualified):
         off, cnt = self._fields[qualified]
@@ -158,9 +171,31 @@ class FoldScoreSets:
 _default = None
 
 
+class NoTablesError(RuntimeError):
+    pass
+
+
+def set_default_tables(tables):
+    """Name the table set `transfer()` draws from (a FoldScoreSets holding the "compiled"
+    constants): FoldScoreSets.load(path) of a real dump, or — explicitly — a synthetic set."""
+    global _default
+    _default = tables
+
+
 def default_tables():
+    """The compiled constants `transfer()` copies.  In the reference they come from the
+    rna-ss-params crate, which this tree does not hold: a table file dumped from that crate
+    (bindings/rust/dump_tables.rs) must be named by $RNAMC_TABLES, or a set installed with
+    set_default_tables().  There is NO silent synthetic fallback: results computed from
+    made-up tables must never look like the reference's."""
     global _default
     if _default is None:
         path = os.environ.get("RNAMC_TABLES")
-        _default = FoldScoreSets.load(path) if path else FoldScoreSets.synthetic(0)
+        if not path:
+            raise NoTablesError(
+                "no scoring tables configured: set $RNAMC_TABLES to a table file dumped from the "
+                "rna-ss-params crate (bindings/rust/dump_tables.rs), or choose synthetic tables "
+                "explicitly (utils.set_default_tables(FoldScoreSets.synthetic(seed)); the CLIs "
+                "take --synthetic-tables SEED)")
+        _default = FoldScoreSets.load(path)
     return _default

@@ -89,6 +89,33 @@ __device__ __forceinline__ float lseC(float sum, float x, const Tab*) {
   r = lo + r;
   return lo == kNegInf ? hi : r;
 }
+// E: no LDS on the chain: the 8 lanes of a group evaluate the 8 cubic pieces of ONE chain
+// speculatively (piece = lane & 7, coefficients in registers), the lane whose interval holds
+// z keeps its result, an OR over the group (3 DPP steps) hands it to all 8 lanes.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_or(unsigned v) {
+  return v | (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+struct PieceRegs { float c0, c1, c2, c3, tlo, thi; };
+__device__ __forceinline__ PieceRegs piece_regs() {
+  const int p = threadIdx.x & 7;
+  PieceRegs r{kCoef[p][0], kCoef[p][1], kCoef[p][2], kCoef[p][3], p ? kBreaks[p - 1] : -1.f, kBreaks[p]};
+  return r;
+}
+__device__ __forceinline__ float lseE(float sum, float x, const PieceRegs& P) {
+  float hi = vmax(sum, x), lo = vmin(sum, x), z = hi - lo;
+  float r = ((P.c0 * z + P.c1) * z + P.c2) * z + P.c3;
+  r = lo + r;
+  const bool sel = (z >= P.tlo) && (z < P.thi);
+  unsigned v = sel ? __float_as_uint(r) : 0u;
+  v = dpp_or<0xB1>(v);    // quad_perm [1,0,3,2]
+  v = dpp_or<0x4E>(v);    // quad_perm [2,3,0,1]
+  v = dpp_or<0x141>(v);   // row_half_mirror
+  // off the chain: the identity piece (z >= 11.862479: lo + z) and the -inf operand
+  const float alt = (lo == kNegInf) ? hi : lo + z;
+  const bool need_alt = (lo == kNegInf) || (z >= 11.862479f);
+  return need_alt ? alt : __uint_as_float(v);
+}
 template <int V, int CH>
 __global__ void __launch_bounds__(64) k(float* out, unsigned long long* cyc, int iters) {
   __shared__ Tab tab;
@@ -96,6 +123,11 @@ __global__ void __launch_bounds__(64) k(float* out, unsigned long long* cyc, int
   float s[CH];
   for (int c = 0; c < CH; c++) s[c] = threadIdx.x * 0.01f + c;
   float x = 0.3f + threadIdx.x * 0.001f;
+  PieceRegs PR = piece_regs();
+  if (V == 4) {  // a chain lives on 8 lanes: same operands on all of them
+    for (int c = 0; c < CH; c++) s[c] = (threadIdx.x >> 3) * 0.08f + c;
+    x = 0.3f + (threadIdx.x >> 3) * 0.008f;
+  }
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; it++) {
 #pragma unroll
@@ -107,6 +139,7 @@ __global__ void __launch_bounds__(64) k(float* out, unsigned long long* cyc, int
         if (V == 1) s[c] = lseB(s[c], xx, &tab);
         if (V == 2) s[c] = lseC(s[c], xx, &tab);
         if (V == 3) s[c] = lseD(s[c], xx, &tab);
+        if (V == 4) s[c] = lseE(s[c], xx, PR);
       }
     }
     x += 0.001f;
@@ -151,6 +184,9 @@ int main() {
   run<0, 3>("A cell-LUT        3 chains");
   run<1, 3>("B ladder+LDS coef 3 chains");
   run<2, 3>("C all-VALU        3 chains");
+  run<4, 1>("E 8-lane speculative 1 chain");
+  run<4, 2>("E 8-lane speculative 2 chains");
+  run<4, 3>("E 8-lane speculative 3 chains");
   run<0, 6>("A cell-LUT        6 chains");
   run<2, 6>("C all-VALU        6 chains");
   return 0;

@@ -1,7 +1,7 @@
 """Generates tests/golden/*.json|npz from the CPU oracle with the seeded synthetic
 tables ("self-golden, synthetic tables": the reference itself cannot run here and
 holds no golden vectors for this path — SURVEY.md §8c).  Usage:
-    python tests/make_golden.py [small|n1024|n4096_turner|n4096_contra]
+    python tests/make_golden.py [small|container|batch|batch2k|n1024|n4096_turner|n4096_contra]
 """
 import hashlib
 import json
@@ -47,6 +47,18 @@ def main(which):
                 arrs[f"trna{idx}_{'contra' if contra else 'turner'}"] = out
                 arrs[f"trna{idx}_{'contra' if contra else 'turner'}_logz"] = np.array([lz], np.float32)
         np.savez_compressed(os.path.join(GOLD, "trna_bpp_synthetic_seed1.npz"), **arrs)
+        return
+    if which == "container":
+        # the RNAMCGLD container of bindings/rust/dump_tables.rs, written from the oracle under
+        # synthetic tables: 6 tRNAs + a seeded random n = 120, three model variants each
+        import golden_io
+        recs = read_fasta(os.path.join(GOLD, "sampled_trnas.fa"))
+        seqs = [s for _, s in recs] + [O.splitmix_seq(120, 120)]
+        out = []
+        for s in seqs:
+            for contra, short in ((False, False), (True, False), (True, True)):
+                out.append((s, contra, short, O.bpp(P.ptr, s, contra, short)[0]))
+        golden_io.write(os.path.join(GOLD, "synthetic_goldens.bin"), out)
         return
     if which == "batch":
         # sequences 0, 1, 3 of the 10k-sequence bench batch (lengths 1653, 1024, 531)

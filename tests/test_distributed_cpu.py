@@ -57,3 +57,28 @@ def test_two_rank_gloo_sharding():
         assert sorted(gathered[0] + gathered[1]) == list(range(400))
     loads = sorted(r[4] for r in res)
     assert loads[1] / loads[0] < 1.01
+
+
+def test_bench_launcher_two_ranks_gloo_dry_run():
+    """`python bench.py --gpus 2` outside torchrun starts the launcher itself (a child process)
+    and relays one JSON line with n_gpus = 2; a world that differs from --gpus is refused."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                          "--backend", "gloo", "--dry-run", "--batch-count", "300"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["dry_run"] is True
+    assert rec["config"]["sequences_all_ranks"] == 300
+    # --gpus 2 inside a one-rank world: refused, non-zero
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                          "--backend", "gloo", "--dry-run", "--batch-count", "300"],
+                         env=env2, capture_output=True, text=True, timeout=300)
+    assert bad.returncode == 2 and "refusing" in bad.stderr

@@ -288,7 +288,7 @@ def test_cli_binaries(ctx, params, trnas, tmp_path):
     from rna_algos_amd.bin.mccaskill_algo import HEADER, fmt_f32
     from rna_algos_amd import utils
     fa = utils.EXAMPLE_FASTA_FILE_PATH
-    utils._default = params  # the table set `transfer()` draws from in this test
+    utils.set_default_tables(params)  # the table set `transfer()` draws from in this test
     out = os.path.join(tmp_path, "bpp.dat")
     assert cli_m.main(["-i", fa, "-o", out, "-c"]) == 0
     text = open(out).read()
