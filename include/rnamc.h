@@ -217,7 +217,7 @@ void rnamc_ctx_destroy(rnamc_ctx* ctx);
 int rnamc_ctx_set_params(rnamc_ctx* ctx, const rnamc_params* params);
 /* Tuning knobs (all optional): name in {"group_max_seqs","group_max_nt","group_ws_bytes",
  * "block_threads","fuse_inside","dual_outside","dual_min_cells","dual_max_diag",
- * "order_inside","order_outside","profile"}; returns RNAMC_ERR_INVALID_ARG for unknown names. */
+ * "order_inside","order_outside","head_lds","head_wmax_in","head_wmax_out","profile"}; returns RNAMC_ERR_INVALID_ARG for unknown names. */
 int rnamc_ctx_set(rnamc_ctx* ctx, const char* name, int64_t value);
 
 /* mccaskill_algo over a batch (src/mccaskill_algo.rs:247-280 for each record, as
@@ -262,6 +262,10 @@ typedef struct rnamc_batch_stats {
    *   small: k_outside<.,7>  all three roles in one kernel (launches too small to split) */
   uint64_t launches_outside_main, launches_outside_tail, launches_outside_small;
   double ms_outside_main, ms_outside_tail, ms_outside_small;
+  /*   head : k_head          2-loop half of the pair probabilities, operand windows staged
+   *                          through LDS (third stream); `main` is then probs_multibranch alone */
+  uint64_t launches_outside_head;
+  double ms_outside_head;
 } rnamc_batch_stats;
 int rnamc_ctx_last_stats(rnamc_ctx* ctx, rnamc_batch_stats* out);
 

@@ -41,10 +41,17 @@ void launch_pair_tail(const DeviceBatch& b, bool contra, uint32_t d0, uint32_t n
                       uint32_t nseq, uint32_t block, hipStream_t st);
 // true when the folds of diagonal d run in the latency form (launch too small to fill the chip)
 bool inside_is_split(uint32_t d, uint32_t max_n, uint32_t nseq);
-// roles: 7 = all three roles in one kernel; 5 = probs_multibranch + pair head; 2 = pair tail
+// roles: 7 = all three roles in one kernel; 5 = probs_multibranch + pair head; 2 = pair tail;
+// 1 = probs_multibranch alone (the pair head then runs as k_head)
 void launch_outside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
                     uint32_t block, bool do_mb, bool do_tail, bool do_head, int roles,
                     hipStream_t st);
+// 2-loop ("probe") halves with their operand windows staged through LDS (k_head): inside the
+// early part of the closing-pair blocks of diagonals d0 .. d0+nd-1, outside (nd = 1) the
+// 2-loop half of the pair probabilities of diagonal d0.  Returns a hipError_t as int.
+int launch_head(const DeviceBatch& b, bool contra, bool outside, uint32_t d0, uint32_t nd,
+                uint32_t max_n, uint32_t nseq, uint32_t wmax, hipStream_t st);
+size_t head_smem_bytes(bool outside, uint32_t wmax);
 void launch_finalize(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, uint32_t dmin_out,
                      hipStream_t st);
 

@@ -248,10 +248,19 @@ struct ProbeFixed {
 // `act`: this lane owns a cell that takes part; lim: largest a+b with a probe on
 // this diagonal (uniform); for OUTSIDE each lane additionally needs k >= 0 and
 // l <= n-1.
-template <bool CONTRA, bool OUTSIDE>
+// LDSW: the operands come from a window staged in LDS by the workgroup (k_head) instead of
+// from global memory: row s of the window holds, for diagonal d-2-s (inside) / d+2+s
+// (outside), the positions the block's lanes can touch, so every element is fetched from
+// HBM once per block instead of once per probe.
+//   inside : win[s * wp + w]  = sums_close(diag d-2-s, offset p0 + 1 + w)           (float)
+//   outside: win2[s * wp + w] = {log prob, sums_close}(diag d+2+s, offset p0 - 31 + w) (float2)
+// wi = i - p0 is the lane's position inside the block's range.
+template <bool CONTRA, bool OUTSIDE, bool LDSW = false>
 __device__ __forceinline__ float probe_fold(const DeviceBatch& b, const Seq& q, uint32_t d,
                                             uint32_t i, bool act, uint32_t lim, float sum,
-                                            float qb_ij, const LseTab* tab, const ProbeTabs& L) {
+                                            float qb_ij, const LseTab* tab, const ProbeTabs& L,
+                                            const float* win = nullptr, uint32_t wp = 0,
+                                            uint32_t wi = 0) {
   const uint32_t n = q.n;
   const uint32_t j = i + d;
   const float* __restrict__ qb = q.m[M_QB];
@@ -330,6 +339,23 @@ __device__ __forceinline__ float probe_fold(const DeviceBatch& b, const Seq& q, 
   };
   auto fetch = [&](PBuf& B, uint32_t ra, uint32_t rb) {
     const uint32_t blast = lim - ra;  // last probe of the row
+    if (LDSW) {
+      // lane address of (row ra, b = 0); successive b are one window row (wp) apart
+      const uint32_t w0 = OUTSIDE ? ra * wp + wi + 30u - ra : ra * wp + wi + ra;
+#pragma unroll
+      for (int u = 0; u < kPU; u++) {
+        const uint32_t bb = min(rb + static_cast<uint32_t>(u), blast);
+        if (OUTSIDE) {
+          const float2 v = reinterpret_cast<const float2*>(win)[w0 + bb * wp];
+          B.ps[u] = v.x;
+          B.xs[u] = v.y;
+        } else {
+          B.xs[u] = win[w0 + bb * wp];
+          B.ps[u] = 0.f;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < kPU; u++) {
       const uint32_t bb = min(rb + static_cast<uint32_t>(u), blast);

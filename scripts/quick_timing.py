@@ -74,6 +74,9 @@ def main():
         ctx.set("dual_min_cells", int(os.environ["DUALMIN"]))
     if os.environ.get("FUSE"):
         ctx.set("fuse_inside", int(os.environ["FUSE"]))
+    for kv in filter(None, os.environ.get("SETS", "").split(",")):
+        k, v = kv.split("=")
+        ctx.set(k, int(v))
     if os.environ.get("BLOCK"):
         ctx.set("block_threads", int(os.environ["BLOCK"]))
     what = sys.argv[1:] or ["n1024", "n4096", "batch256"]

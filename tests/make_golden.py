@@ -75,6 +75,23 @@ def main(which):
             json.dump({"param_seed": PARAM_SEED, "cases": res}, fh, indent=1)
         print(json.dumps(res, indent=1))
         return
+    if which == "batch2k":
+        # one of the LONGEST members of the 10k bench batch: it sits inside the first lock-step
+        # group (the ~740 longest sequences, where the workspace cap and the multi-kernel
+        # outside path engage)
+        from rna_algos_amd import workloads as W
+        lens = W.batch_lengths(10000)
+        idx = int(np.argsort(-lens, kind="stable")[5])
+        s = W.synthetic_seq(int(lens[idx]), (10000 << 32) + idx)
+        res = {}
+        for contra in (0, 1):
+            t0 = time.time()
+            out, lz = O.bpp(P.ptr, s, contra, 0)
+            res[f"batch{idx}_{'contra' if contra else 'turner'}"] = summary(out, lz, len(s), time.time() - t0)
+            with open(os.path.join(GOLD, "checksums_batch2k.json"), "w") as fh:
+                json.dump({"param_seed": PARAM_SEED, "batch_count": 10000, "cases": res}, fh, indent=1)
+        print(json.dumps(res, indent=1))
+        return
     cases = {"n1024": [(1024, 1024, 1), (1024, 1024, 0)], "n4096_turner": [(4096, 4096, 0)],
              "n4096_contra": [(4096, 4096, 1)]}[which]
     res = {}

@@ -502,3 +502,117 @@ def test_one_context_from_many_threads(ctx, params, trnas):
     for (packed, lz), (ref, rz) in zip(got, want):
         assert_same(packed, ref)
         assert lz.view(np.uint32) == np.float32(rz).view(np.uint32)
+
+
+@pytest.mark.parametrize("contra,short", [(False, False), (True, False), (True, True)])
+def test_lds_staged_probe_windows_bit_exact(params, contra, short):
+    """Large launches run the 2-loop halves as k_head: the <= 31 diagonal windows a
+    workgroup's cells can touch are staged in LDS once and probed from there.  Forced onto
+    every launch of a ragged batch, with windows so narrow (64 positions) that a workgroup
+    needs several staging rounds, and with the default width: same bits as the oracle and as
+    the global-gather form; the per-kernel accounting sees the head kernel."""
+    from rna_algos_amd.mccaskill_algo import Context
+    rng = np.random.default_rng(177 + int(contra) + 2 * int(short))
+    lens = list(rng.integers(40, 420, 48)) + [1, 3, 6, 33, 64, 65, 700]
+    seqs = [rng.integers(0, 4, int(n)).astype(np.uint8) for n in lens]
+    # low-complexity members: dense (GC repeats: every second cell pairs) and empty lists
+    seqs += [np.tile(np.array([2, 1], np.uint8), 150), np.zeros(90, np.uint8),
+             np.tile(np.array([2, 3, 3, 2, 1], np.uint8), 70)]
+    ctx = Context(params, device=0)
+    try:
+        ctx.set("dual_min_cells", 0)
+        ctx.set("head_lds", 0)
+        base, logz0 = ctx.bpp_batch(seqs, contra, short)
+        ctx.set("head_lds", 1)
+        ctx.set("profile", 2)
+        runs = []
+        for wmax in (64, 448):
+            ctx.set("head_wmax_in", wmax)
+            ctx.set("head_wmax_out", wmax)
+            runs.append(ctx.bpp_batch(seqs, contra, short))
+            st = ctx.stats()
+            assert st["launches_outside_head"] > 300 and st["ms_outside_head"] > 0
+            assert st["launches_outside_main"] == st["launches_outside_tail"]
+    finally:
+        ctx.close()
+    ref, ref_logz = O.bpp_batch(params.ptr, seqs, contra, short, n_threads=16)
+    for mats, logz in runs:
+        for s, a, m, r in zip(seqs, base, mats, ref):
+            assert np.array_equal(np.asarray(a.packed).view(np.uint32),
+                                  np.asarray(m.packed).view(np.uint32)), f"n={len(s)}"
+            assert_same(m.packed, r, f"n={len(s)}")
+        assert np.array_equal(np.asarray(logz).view(np.uint32), np.asarray(ref_logz).view(np.uint32))
+    assert np.array_equal(np.asarray(logz0).view(np.uint32), np.asarray(ref_logz).view(np.uint32))
+
+
+def test_bench_scale_first_group_golden(params):
+    """The bench's own first lock-step group at default knobs: the 800 longest sequences of
+    the 10k batch (1900..2048 nt), so that the 64 GB workspace cap cuts the group, the
+    two-diagonal inside schedule, the multi-kernel outside sweep and k_head all engage.  A
+    2048-nt member INSIDE that group is compared with the oracle's committed checksum
+    (tests/make_golden.py batch2k: ~4 min of oracle time per model), both models.  Runs
+    through the host-buffer entry (results of group g are drained while group g+1 sweeps)."""
+    from rna_algos_amd import workloads as W
+    from rna_algos_amd.mccaskill_algo import Context
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "checksums_batch2k.json")))
+    lens = W.batch_lengths(10000)
+    order = np.argsort(-lens, kind="stable")[:800]
+    seqs = [W.synthetic_seq(int(lens[i]), (10000 << 32) + int(i)) for i in order]
+    ln = np.array([len(s) for s in seqs], dtype=np.uint64)
+    offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    np.cumsum(ln, out=offsets[1:])
+    out_offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    np.cumsum(ln * (ln + np.uint64(1)) // np.uint64(2), out=out_offsets[1:])
+    bases = np.concatenate(seqs)
+    out = np.empty(int(out_offsets[-1]), dtype=np.float32)
+    logz = np.empty(len(seqs), dtype=np.float32)
+    ctx = Context(params, device=0)
+    try:
+        for name, info in gold["cases"].items():
+            idx = int(name.split("_")[0][len("batch"):])
+            contra = name.endswith("contra")
+            x = int(np.nonzero(order == idx)[0][0])
+            assert 0 < x < 700, "the golden member must sit inside the first group"
+            out.fill(7.0)
+            ctx.bpp_batch_into(bases, offsets, contra, False, out, out_offsets, logz)
+            st = ctx.stats()
+            assert st["n_groups"] >= 2, "the workspace cap did not cut the group"
+            got = out[int(out_offsets[x]):int(out_offsets[x + 1])].copy()
+            assert int(np.float32(logz[x]).view(np.uint32)) == info["log_partition_bits"], name
+            assert int((got >= -0.5).sum()) == info["present"]
+            got[got >= 0.9999] = 1.0
+            assert hashlib.sha256(got.tobytes()).hexdigest() == info["sha256"], name
+            # every triangle was written (no slot keeps the fill value), also in the last group
+            tail = out[int(out_offsets[-2]):]
+            assert not np.any(out[::4099] == 7.0) and not np.any(tail == 7.0)
+    finally:
+        ctx.close()
+
+
+def test_long_sequence_invariants(ctx):
+    """n = 8192, beyond any oracle run: the key set is exactly the canonical pairs of span
+    >= 5, every probability lies in the reference's own test range (tests/tests.rs:33,38), no
+    base pairs with total probability above 1 + eps, and a second run gives the same bits."""
+    from rna_algos_amd import workloads as W
+    n = 8192
+    s = W.synthetic_seq(n, n)
+    mats, logz = ctx.bpp_batch([s], False, False)
+    m = mats[0].packed
+    mats2, logz2 = ctx.bpp_batch([s], False, False)
+    assert np.array_equal(m.view(np.uint32), mats2[0].packed.view(np.uint32))
+    assert np.float32(logz[0]).view(np.uint32) == np.float32(logz2[0]).view(np.uint32)
+    assert np.isfinite(logz[0])
+    off = 0
+    rowsum = np.zeros(n)
+    for d in range(n):
+        row = m[off:off + n - d]
+        a, b = s[:n - d].astype(int), s[d:].astype(int)
+        canon = ((a + b == 3) | (a + b == 5)) & (d >= 4)
+        assert np.array_equal(row >= -0.5, canon), d
+        r = np.where(canon, row.astype(np.float64), 0.0)
+        rowsum[:n - d] += r
+        rowsum[d:] += r
+        off += n - d
+    vals = m[m >= -0.5]
+    assert vals.min() >= -0.001 and vals.max() < 1.001
+    assert rowsum.max() < 1.01
