@@ -81,6 +81,11 @@ struct rnamc_ctx {
   // as k_head (operand windows staged through LDS) on a stream of their own; head_wmax_* =
   // positions a workgroup's window may span (sets its LDS footprint)
   int64_t head_lds = 0;
+  // latency forms (rnamc_latency.h) for groups that cannot fill the chip: 0 never, 1 when the
+  // group's longest diagonal holds at most lat_max_cells cells over all its sequences, 2 always
+  int64_t latency_mode = 1;
+  int64_t lat_max_cells = 16384;
+  int64_t lat_inside = 0;  // the inside sweep of such a group takes its wave-per-chain form too
   int64_t head_wmax_in = 448, head_wmax_out = 448;
   // role mask of timing experiments (bit0 folds, 1 pair block, 2 mb, 3 pair probs); settable
   // only in builds with -DRNAMC_DEBUG_KNOBS (make DEBUG_KNOBS=1), constant 15 otherwise
@@ -350,7 +355,49 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
         }
       }
     };
-    for (uint32_t d = dmin_in; d < gmax;) {
+    // Latency-form group: folds(d) on `st` (k_inside_lat) beside the pair block of d+1 on
+    // aux_stream; folds(d) need the pair block of d (aux, step before), the pair block of
+    // d+1 needs the folds of d-1 (st, step before).
+    const bool lat = c->latency_mode == 2 ||
+                     (c->latency_mode == 1 &&
+                      static_cast<uint64_t>(nseq) * gmax <= static_cast<uint64_t>(c->lat_max_cells));
+    const bool lat_in = lat && c->lat_inside != 0;
+    if (lat_in) {
+      bool have_a = false, have_b = false;
+      for (uint32_t d = dmin_in; d < gmax; d++) {
+        need_pairs(d);  // (only the first diagonal finds work here)
+        const bool pair_next = heads_done < static_cast<int64_t>(d) + 1 && d + 1 < gmax;
+        const uint32_t pv = (d + ring - 1) % ring, cu = d % ring;
+        if (pair_next && do_pair) {
+          if (!have_a) {  // everything so far is on `st`
+            HIPCHK(hipEventRecord(c->ev_a[pv], st));
+            have_a = true;
+          }
+          HIPCHK(hipStreamWaitEvent(c->aux_stream, c->ev_a[pv], 0));
+          launch_inside(b, contra, d, gmax, active(d + 1), block, false, true, c->aux_stream);
+          c->stats.launches_inside++;
+        }
+        if (have_b) HIPCHK(hipStreamWaitEvent(st, c->ev_b[pv], 0));
+        if (do_sums) {
+          // (the combine of diagonal d-1 rides along: sequences that end at d-1 included)
+          launch_inside_lat(b, contra, d, gmax, active(d >= 1 ? d - 1 : 0), true, d > dmin_in, st);
+          c->stats.launches_inside++;
+        }
+        HIPCHK(hipEventRecord(c->ev_a[cu], st));
+        have_a = true;
+        if (pair_next) {
+          HIPCHK(hipEventRecord(c->ev_b[cu], c->aux_stream));
+          have_b = true;
+          pairs_done = heads_done = d + 1;
+        } else {
+          have_b = false;
+        }
+      }
+      if (have_b) HIPCHK(hipStreamWaitEvent(st, c->ev_b[(gmax - 1) % ring], 0));
+      if (do_sums && gmax > dmin_in)  // combine of the last diagonal
+        launch_inside_lat(b, contra, gmax, gmax, active(gmax - 1), false, true, st);
+    }
+    for (uint32_t d = dmin_in; d < gmax && !lat_in;) {
       const bool fuse = c->fuse_inside != 0 && d >= 2 && d + 1 < gmax &&
                         !inside_is_split(d, gmax, active(d));
       if (fuse) {
@@ -427,7 +474,38 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
         c->kev_class.push_back(cls);
       };
       bool tri = false;  // the previous diagonal ran as three kernels (k_head on head_stream)
-      for (uint32_t d = gmax + 1; d-- > dmin_out;) {
+      if (lat) {
+        // latency-form group: {probs_multibranch, multibranch half of the pair probabilities}
+        // of diagonal d on `st` (k_outside_lat) beside the 2-loop half of diagonal d-1 on
+        // aux_stream; both need both of diagonal d+1
+        bool first = true;
+        for (uint32_t d = gmax + 1; d-- > dmin_out;) {
+          const bool head = d >= 1 && d - 1 >= dmin_out;
+          const uint32_t na = active(d >= 1 ? d - 1 : 0);
+          const uint32_t pv = (d + 1) % ring, cu = d % ring;
+          if (first) {
+            HIPCHK(hipEventRecord(c->ev_a[pv], st));
+          } else {
+            HIPCHK(hipStreamWaitEvent(st, c->ev_b[pv], 0));
+          }
+          HIPCHK(hipStreamWaitEvent(c->aux_stream, c->ev_a[pv], 0));
+          if (d < gmax) {
+            timed(0, st, [&]() { launch_outside_lat(b, contra, d, gmax, active(d), r_mb, r_tail, st); });
+            c->stats.launches_outside++;
+          }
+          HIPCHK(hipEventRecord(c->ev_a[cu], st));
+          if (head && r_head) {
+            timed(3, c->aux_stream, [&]() {
+              launch_outside(b, contra, d, gmax, na, block, false, false, true, 4, c->aux_stream);
+            });
+            c->stats.launches_outside++;
+          }
+          HIPCHK(hipEventRecord(c->ev_b[cu], c->aux_stream));
+          first = false;
+        }
+        if (!first) HIPCHK(hipStreamWaitEvent(st, c->ev_b[dmin_out % ring], 0));
+      }
+      for (uint32_t d = gmax + 1; d-- > dmin_out && !lat;) {
         const bool head = d >= 1 && d - 1 >= dmin_out;
         const uint32_t na = active(d >= 1 ? d - 1 : 0);
         // worth it where the 2-loop blocks dominate a launch: the folds of a cell grow with
@@ -744,6 +822,12 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     c->fuse_inside = value;
   } else if (k == "head_lds") {
     c->head_lds = value;
+  } else if (k == "latency_mode" && value >= 0 && value <= 2) {
+    c->latency_mode = value;
+  } else if (k == "lat_max_cells" && value >= 0) {
+    c->lat_max_cells = value;
+  } else if (k == "lat_inside") {
+    c->lat_inside = value;
   } else if ((k == "head_wmax_in" || k == "head_wmax_out") && value >= 64 && value <= 4096) {
     // the window must fit the CU's 160 KB of LDS beside the tables
     if (head_smem_bytes(k == "head_wmax_out", static_cast<uint32_t>(value)) > 160u * 1024u)

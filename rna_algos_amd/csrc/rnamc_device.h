@@ -42,7 +42,7 @@ void launch_pair_tail(const DeviceBatch& b, bool contra, uint32_t d0, uint32_t n
 // true when the folds of diagonal d run in the latency form (launch too small to fill the chip)
 bool inside_is_split(uint32_t d, uint32_t max_n, uint32_t nseq);
 // roles: 7 = all three roles in one kernel; 5 = probs_multibranch + pair head; 2 = pair tail;
-// 1 = probs_multibranch alone (the pair head then runs as k_head)
+// 1 = probs_multibranch alone (the pair head then runs as k_head); 4 = pair head alone
 void launch_outside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
                     uint32_t block, bool do_mb, bool do_tail, bool do_head, int roles,
                     hipStream_t st);
@@ -52,6 +52,13 @@ void launch_outside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_
 int launch_head(const DeviceBatch& b, bool contra, bool outside, uint32_t d0, uint32_t nd,
                 uint32_t max_n, uint32_t nseq, uint32_t wmax, hipStream_t st);
 size_t head_smem_bytes(bool outside, uint32_t wmax);
+// Latency forms for groups too small to fill the chip (rnamc_latency.h): one wave per fold
+// chain.  A group that uses them uses them on EVERY diagonal (they keep W dense, and complete
+// sums_1ormore_basepairs of diagonal d-1 in the launch of diagonal d).
+void launch_inside_lat(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
+                       bool do_chains, bool do_combine, hipStream_t st);
+void launch_outside_lat(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
+                        bool do_mb, bool do_tail, hipStream_t st);
 void launch_finalize(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, uint32_t dmin_out,
                      hipStream_t st);
 

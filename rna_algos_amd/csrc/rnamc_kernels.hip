@@ -1481,6 +1481,63 @@ __global__ void __launch_bounds__(kHeadBlock)
   }
 }
 
+#include "rnamc_latency.h"
+
+// Latency-form launches, one wave per workgroup (rnamc_latency.h).
+// Inside, diagonal d: blocks [0, 3 cells) one (cell, role) chain each; then one lane per cell of
+// diagonal d-1 for the combine that completes sums_1ormore_basepairs (do_combine).
+template <bool CONTRA>
+__global__ void __launch_bounds__(64) k_inside_lat(DeviceBatch b, uint32_t d, uint32_t cells_max,
+                                                   uint32_t nseq, int do_chains, int do_combine) {
+  __shared__ LseTab tabs;
+  const uint32_t bx = blockIdx.x / nseq;
+  const uint32_t which = blockIdx.x - bx * nseq;
+  const Seq q = load_seq(b, which);
+  const uint32_t n = q.n;
+  if (bx < 3u * cells_max) {
+    const uint32_t i = bx / 3u, role = bx - 3u * i;
+    if (!do_chains || d >= n || i >= n - d) return;
+    const Piece8 P8 = load_piece8();
+    inside_chain_lat<CONTRA>(b, q, d, i, role, P8);
+  } else {
+    if (!do_combine || d == 0 || d - 1 >= n) return;
+    const uint32_t i0 = (bx - 3u * cells_max) * 64u;
+    if (i0 >= n - (d - 1)) return;
+    load_lse_table(&tabs);
+    const uint32_t i = i0 + (threadIdx.x & 63u);
+    if (i < n - (d - 1)) inside_combine_lat(q, d - 1, i, &tabs);
+  }
+}
+
+// Outside, diagonal d: blocks [0, cells): multibranch half of the pair probability of one
+// listed cell each, longest chains (largest i) first; then one block per cell for
+// probs_multibranch{,2}.
+template <bool CONTRA>
+__global__ void __launch_bounds__(64) k_outside_lat(DeviceBatch b, uint32_t d, uint32_t cells_max,
+                                                    uint32_t nseq, int do_mb, int do_tail) {
+  const uint32_t bx = blockIdx.x / nseq;
+  const uint32_t which = blockIdx.x - bx * nseq;
+  const Seq q = load_seq(b, which);
+  const uint32_t n = q.n;
+  if (d >= n) return;
+  const Piece8 P8 = load_piece8();
+  if (bx < cells_max) {
+    if (!do_tail) return;
+    const uint32_t cnt = q.ccnt[d];
+    if (bx >= cnt) return;
+    const uint32_t i = uni(static_cast<uint32_t>(q.cidx[tri_off(n, d) + (cnt - 1u - bx)]));
+    // the launch's critical path: this wave issues whenever it can, the probs_multibranch
+    // waves that share its SIMD take the gaps
+    __builtin_amdgcn_s_setprio(3);
+    outside_tail_lat<CONTRA>(b, q, d, i, P8);
+  } else {
+    if (!do_mb) return;
+    const uint32_t i = bx - cells_max;
+    if (i >= n - d) return;
+    outside_mb_lat<CONTRA>(b, q, d, i, P8);
+  }
+}
+
 // final map (src/mccaskill_algo.rs:608 / 721) + log partition function.  A pair is
 // in the reference's SparseProbMat iff it got a probability, i.e. iff it is in
 // sums_close and its span was visited by the outside sweep (602-604 / 715-717).
@@ -1609,16 +1666,51 @@ void launch_outside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_
   hipLaunchKernelGGL((k_outside<C, R>), g, dim3(block), 0, st, b, d, nb, nh, nseq, a0, a1, a2)
   if (contra) {
     if (roles == 5) RNAMC_LAUNCH_OUT(true, 5);
+    else if (roles == 4) RNAMC_LAUNCH_OUT(true, 4);
     else if (roles == 1) RNAMC_LAUNCH_OUT(true, 1);
     else if (roles == 2) RNAMC_LAUNCH_OUT(true, 2);
     else RNAMC_LAUNCH_OUT(true, 7);
   } else {
     if (roles == 5) RNAMC_LAUNCH_OUT(false, 5);
+    else if (roles == 4) RNAMC_LAUNCH_OUT(false, 4);
     else if (roles == 1) RNAMC_LAUNCH_OUT(false, 1);
     else if (roles == 2) RNAMC_LAUNCH_OUT(false, 2);
     else RNAMC_LAUNCH_OUT(false, 7);
   }
 #undef RNAMC_LAUNCH_OUT
+}
+
+// latency forms (rnamc_latency.h): the fold chains of diagonal d (do_chains) and the combine
+// that completes sums_1ormore_basepairs of diagonal d-1 (do_combine)
+void launch_inside_lat(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
+                       bool do_chains, bool do_combine, hipStream_t st) {
+  if (nseq == 0) return;
+  const uint32_t cells = (do_chains && d < max_n) ? max_n - d : 0;
+  const uint32_t cb = (do_combine && d >= 1 && d - 1 < max_n) ? (max_n - d + 1 + 63) / 64 : 0;
+  if (3 * cells + cb == 0) return;
+  const dim3 g((3 * cells + cb) * nseq, 1, 1);
+  const int a0 = do_chains ? 1 : 0, a1 = do_combine ? 1 : 0;
+  if (contra) {
+    hipLaunchKernelGGL(k_inside_lat<true>, g, dim3(64), 0, st, b, d, cells, nseq, a0, a1);
+  } else {
+    hipLaunchKernelGGL(k_inside_lat<false>, g, dim3(64), 0, st, b, d, cells, nseq, a0, a1);
+  }
+}
+
+// probs_multibranch{,2} and the multibranch half of the pair probabilities of diagonal d, one
+// wave per cell / listed cell
+void launch_outside_lat(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
+                        bool do_mb, bool do_tail, hipStream_t st) {
+  if (d >= max_n || nseq == 0) return;
+  const uint32_t cells = max_n - d;
+  const dim3 g(2 * cells * nseq, 1, 1);
+  const int a0 = do_mb ? 1 : 0, a1 = do_tail ? 1 : 0;
+  const size_t lds_cap = 0;
+  if (contra) {
+    hipLaunchKernelGGL(k_outside_lat<true>, g, dim3(64), lds_cap, st, b, d, cells, nseq, a0, a1);
+  } else {
+    hipLaunchKernelGGL(k_outside_lat<false>, g, dim3(64), lds_cap, st, b, d, cells, nseq, a0, a1);
+  }
 }
 
 // LDS bytes of one k_head workgroup: tables + 31 window rows of (wmax + 32) elements

@@ -1,0 +1,305 @@
+// rnamc_latency.h — latency forms of the folds, for lock-step groups too small to fill the
+// chip (a single long sequence: BASELINE config 3, n = 4096).  Device code, included by
+// rnamc_kernels.hip inside namespace rnamc { namespace { ... } }.
+//
+// Such a group is bound by the LENGTH of the dependent fold chains the reference's summation
+// order dictates (src/mccaskill_algo.rs:344-374 / 468-512 inside: n^2/2 steps; 594-601 /
+// 701-714 outside: 3 n^2/2 steps), not by HBM or VALU throughput: > 95 % of the chip idles.
+// So a whole WAVE is spent on ONE chain (same operations on the chain's value, same order,
+// bit for bit; every lane holds the same running sum, control flow is scalar):
+//  * 89 % of the outside multibranch fold steps and 68 % of all others add a term more than
+//    11.862479 below the running sum, where logsumexp is `min + (max - min)`
+//    (src/utils.rs:589-591).  With one chain per wave that case is a scalar branch away and
+//    costs 6 vector instructions (a wave that carried 64 independent chains would find some
+//    lane outside it at every step).
+//  * otherwise lane p (mod 8) evaluates cubic piece p of ln_exp_1p (src/utils.rs:602-627)
+//    speculatively, coefficients in registers; the lane whose interval holds z keeps the
+//    result and an OR over each group of 8 lanes (3 DPP steps) hands it to every lane: no
+//    LDS table on the critical path (137 instead of 208 cycles per dependent step,
+//    profiles/r02_ubench_lse_latency.txt).
+//  * operands of the next 32-64 steps are in flight in registers (a step takes 45-140
+//    cycles, a round trip to L2 / HBM 2000-4000); every lane loads the same address.
+#ifndef RNAMC_LATENCY_H
+#define RNAMC_LATENCY_H
+
+struct Piece8 {
+  float c0, c1, c2, c3;  // cubic piece (threadIdx & 7)
+  float tlo, thi;        // its interval [tlo, thi)
+};
+
+__device__ __forceinline__ Piece8 load_piece8() {
+  const int p = static_cast<int>(threadIdx.x & 7u);
+  Piece8 r;
+  r.c0 = kLseCoef[p][0];
+  r.c1 = kLseCoef[p][1];
+  r.c2 = kLseCoef[p][2];
+  r.c3 = kLseCoef[p][3];
+  r.tlo = p ? kLseBreaks[p - 1] : -1.f;  // z >= 0 always
+  r.thi = kLseBreaks[p];
+  return r;
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_or(uint32_t v) {
+  return v | static_cast<uint32_t>(
+                 __builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xF, 0xF, false));
+}
+
+// Operands: lane l of the wave loads step k0 + l (one coalesced load per 64 steps and
+// stream), the chain takes them lane by lane through v_readlane: the next 64-128 steps are in
+// flight in four registers, far beyond any memory latency.
+// A loaded register handed on through an opaque move: the compiler waits for exactly that
+// load HERE (a counted vmcnt in straight-line code) instead of draining every load in flight
+// at the top of the loop that consumes it.
+__device__ __forceinline__ float pin(float v) {
+  float o;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(o) : "v"(v));
+  return o;
+}
+
+__device__ __forceinline__ float lane_val(float v, uint32_t lane) {
+  return __uint_as_float(static_cast<uint32_t>(
+      __builtin_amdgcn_readlane(static_cast<int>(__float_as_uint(v)), static_cast<int>(lane))));
+}
+
+constexpr uint32_t kLseThrBits = 0x413DCCB7u;  // 11.862479f (LOGSUMEXP_THRESHOLD_UPPER)
+
+// One fold step sum ⊕ x of the wave's chain: `sum` and `x` are the same in every lane.
+__device__ __forceinline__ float lse_u(float sum, float x, const Piece8& P) {
+  const float hi = vmax(sum, x);
+  const float lo = vmin(sum, x);
+  const float z = hi - lo;  // >= 0; +inf or NaN when lo is -inf
+  // 11.862479 <= z < +inf as one unsigned compare on the bits (z >= 0, NaN sorts above inf)
+  const bool far = (__float_as_uint(z) - kLseThrBits) < (0x7F800000u - kLseThrBits);
+  if (__builtin_expect(__ballot(far) != 0ull, 1)) return lo + z;  // identity piece, finite operands
+  // z < 11.862479: the 8 cubic pieces, one per lane (mod 8); or lo = -inf.  The lanes whose
+  // interval holds z (one per group of 8, all with the same value) are found by a ballot,
+  // the first of them hands its result to the whole wave through an SGPR.
+  float r = ((P.c0 * z + P.c1) * z + P.c2) * z + P.c3;
+  r = lo + r;
+  const unsigned long long sel = __ballot((z >= P.tlo) && (z < P.thi));
+  if (sel == 0ull) return hi;  // z is +inf or NaN: lo is -inf, the sum is hi
+  return lane_val(r, static_cast<uint32_t>(__builtin_ctzll(sel)));
+}
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) {
+  return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v)));
+}
+
+constexpr int kULat = 16;  // fold steps per operand buffer (two buffers)
+
+// ----------------------------------------------------------------------------
+// inside: one wave per (cell, role) of diagonal d
+//   role 0: sums_rightmost_basepairs_external (CONTRAfold: its own fold) and sums_external
+//   role 1: (CONTRAfold: sums_rightmost_basepairs_multibranch and) the first sum of 364-374 /
+//           499-512, parked in the sums_1ormore slot until the combine below
+//   role 2: sums_multibranch
+// Same operations per chain as inside_sums_cell.
+template <bool CONTRA>
+__device__ __forceinline__ void inside_chain_lat(const DeviceBatch& b, const Seq& q, uint32_t d,
+                                                 uint32_t i, uint32_t role, const Piece8& P8) {
+  const uint32_t n = q.n;
+  const uint32_t od = tri_off(n, d) + i;
+  const float* __restrict__ zre = q.m[M_ZRE];
+  const float* __restrict__ zrm = q.m[CONTRA ? M_ZRM : M_ZRE];
+  const float* __restrict__ qa = q.m[M_QA];
+  const bool lane0 = (threadIdx.x & 63u) == 0u;
+  float zr = kNegInf, c = 0.f, mun = 0.f;
+  if (!CONTRA) {
+    // sums_rightmost_basepairs_external(i,j) = that of (i,j-1) extended by one step (344-351)
+    const float prev = (d >= 1) ? zre[tri_off(n, d - 1) + i] : kNegInf;
+    zr = lse_u(prev, qa[od], P8);
+    if (lane0 && role == 0) q.m[M_ZRE][od] = zr;
+    c = b.params->turner.coeff_num_branches;
+  } else {
+    const rnamc_fold_score_sets& f = b.params->contra;
+    mun = f.multibranch_score_unpair;
+    if (role < 2) {
+      // (468-486): x + P + Q * (j - k), (P, Q) = (ext_bp, ext_unpair) / (mb_bp, mb_unpair)
+      const float Pc = (role == 0) ? f.external_score_basepair : f.multibranch_score_basepair;
+      const float Qc = (role == 0) ? f.external_score_unpair : mun;
+      struct ABuf {
+        float xs[kULat];
+      };
+      uint32_t t = pingpong<ABuf, kULat>(
+          1u, d / kULat,
+          [&](ABuf& B, uint32_t t0) {
+#pragma unroll
+            for (int u = 0; u < kULat; u++) B.xs[u] = qa[tri_off(n, t0 + u) + i];
+          },
+          [&](const ABuf& B, uint32_t t0) {
+#pragma unroll
+            for (int u = 0; u < kULat; u++)
+              zr = lse_u(zr, B.xs[u] + Pc + Qc * static_cast<float>(d - t0 - u), P8);
+          });
+      for (; t <= d; t++)
+        zr = lse_u(zr, qa[tri_off(n, t) + i] + Pc + Qc * static_cast<float>(d - t), P8);
+      if (lane0) q.m[role == 0 ? M_ZRE : M_ZRM][od] = zr;
+    }
+  }
+  // the walk k = i + t:  Zr[k][j] -> diagonal d-t, offset i+t;  Z/Q1[i][k-1] -> diagonal t-1, offset i
+  float acc;
+  if (role == 0) {
+    acc = CONTRA ? lse_u(b.params->contra.external_score_unpair * static_cast<float>(d + 1), zr + 0.f, P8)
+                 : lse_u(0.f, zr + 0.f, P8);  // k = i: Z[i][i-1] is the lower-triangle 0
+  } else if (role == 1) {
+    acc = CONTRA ? zr : zr + c;
+  } else {
+    acc = kNegInf;
+  }
+  const float* __restrict__ pa = (CONTRA && role != 0) ? zrm : zre;
+  const float* __restrict__ pb = q.m[role == 0 ? M_Z : M_Q1D];
+  auto step = [&](float ra, float rb, uint32_t t) {
+    float term;
+    if (!CONTRA) {
+      term = (role == 0) ? ra + rb : (role == 1 ? ra + c : rb + (ra + c));
+    } else {
+      term = (role == 1) ? ra + mun * static_cast<float>(t) : rb + ra;
+    }
+    acc = lse_u(acc, term, P8);
+  };
+  struct SBuf {
+    float ra[kULat], rb[kULat];
+  };
+  uint32_t t = pingpong<SBuf, kULat>(
+      1u, d >= 1 ? (d - 1) / kULat : 0u,
+      [&](SBuf& B, uint32_t t0) {
+#pragma unroll
+        for (int u = 0; u < kULat; u++) {
+          B.ra[u] = pa[tri_off(n, d - t0 - u) + t0 + u + i];
+          B.rb[u] = pb[tri_off(n, t0 + u - 1) + i];
+        }
+      },
+      [&](const SBuf& B, uint32_t t0) {
+#pragma unroll
+        for (int u = 0; u < kULat; u++) step(B.ra[u], B.rb[u], t0 + u);
+      });
+  for (; t < d; t++) step(pa[tri_off(n, d - t) + t + i], pb[tri_off(n, t - 1) + i], t);
+  if (lane0) {
+    if (role == 0) q.m[M_Z][od] = acc;
+    if (role == 1) q.m[M_Q1D][od] = acc;  // parked: inside_combine_lat turns it into sums_1ormore
+    if (role == 2) q.m[M_QM][od] = acc;
+  }
+}
+
+// sums_1ormore_basepairs(i,j) = parked first sum ⊕ sums_multibranch (374 / 512), both layouts.
+// One lane per cell; runs in the launch of the NEXT diagonal (whose folds read nothing newer
+// than diagonal d-1 of this matrix).
+__device__ __forceinline__ void inside_combine_lat(const Seq& q, uint32_t d, uint32_t i,
+                                                   const LseTab* tab) {
+  const uint32_t od = tri_off(q.n, d) + i;
+  const float q1v = lse(q.m[M_Q1D][od], q.m[M_QM][od], tab);
+  q.m[M_Q1D][od] = q1v;
+  if (i >= 1) q.m[M_Q1C][col_off(i + d) + i - 1] = q1v;
+}
+
+// ----------------------------------------------------------------------------
+// outside, probs_multibranch{,2} of one cell per wave (src/mccaskill_algo.rs:540-557 /
+// 641-661).  Only the partners k of base i are folded (scalar scan of the 2-bit packed
+// sequence); an absent pair is a map miss in the reference too.  In a latency-form group
+// W = (P + mbclose) - Qb is stored DENSE (by position, not by list index: every launch of
+// the group uses these forms).
+template <bool CONTRA>
+__device__ __forceinline__ void outside_mb_lat(const DeviceBatch& b, const Seq& q, uint32_t d,
+                                               uint32_t i, const Piece8& P8) {
+  const uint32_t n = q.n;
+  const uint32_t j = i + d;
+  const uint32_t lane = threadIdx.x & 63u;
+  const float* __restrict__ q1d = q.m[M_Q1D];
+  const float* __restrict__ w = q.m[M_W];
+  const uint8_t* __restrict__ s = q.s;
+  const float mun = CONTRA ? b.params->contra.multibranch_score_unpair : 0.f;
+  const uint32_t cnt = n - 1u - j;  // steps t = 1 .. cnt, k = j + t
+  // partners of base a as a 4-bit set: A:{U} C:{G} G:{C,U} U:{A,G}
+  const uint32_t pairmask = (0x5A48u >> (4u * s[i])) & 15u;
+  float pm = kNegInf, pm2 = kNegInf;
+  // Blocks of 64 steps: lane l owns step t0 + l — it loads that step's two operands and
+  // decides whether base k pairs with base i; a ballot gives the block's partner set, whose
+  // members the chain then visits in ascending k through scalar bit scans and v_readlane.
+  struct MBuf {
+    float x, r;
+    uint32_t has;
+  };
+  (void)pingpong<MBuf, 64, true>(
+      1u, (cnt + 63u) / 64u,
+      [&](MBuf& B, uint32_t t0) {
+        const uint32_t t = t0 + lane;
+        const bool in = t <= cnt;
+        const uint32_t tt = in ? t : cnt;  // (cnt >= 1 here)
+        B.x = w[tri_off(n, d + tt) + i];
+        B.r = q1d[tri_off(n, tt >= 2u ? tt - 2u : 0u) + d + 1u + i];
+        B.has = (in && ((pairmask >> s[j + tt]) & 1u)) ? 1u : 0u;
+      },
+      [&](const MBuf& B, uint32_t t0) {
+        const float bx = pin(B.x), br = pin(B.r);
+        unsigned long long m = __ballot(B.has != 0u);
+        while (m) {
+          const uint32_t l = static_cast<uint32_t>(__builtin_ctzll(m));
+          m &= m - 1ull;
+          const uint32_t t = t0 + l;
+          const float x = lane_val(bx, l);
+          // t = 1: sums_1ormore_basepairs[j+1][j] is the empty interval: only pm2 moves
+          if (t >= 2u) pm = lse_u(pm, x + lane_val(br, l), P8);
+          pm2 = lse_u(pm2, CONTRA ? x + mun * static_cast<float>(t - 1u) : x, P8);
+        }
+      });
+  if (lane == 0u) reinterpret_cast<float2*>(q.m[M_PM])[col_off(j) + i] = make_float2(pm, pm2);
+}
+
+// ----------------------------------------------------------------------------
+// outside, multibranch half of the pair probability of one listed cell per wave
+// (src/mccaskill_algo.rs:594-605 / 701-718): ONE chain of three fold steps per k.
+template <bool CONTRA>
+__device__ __forceinline__ void outside_tail_lat(const DeviceBatch& b, const Seq& q, uint32_t d,
+                                                 uint32_t i, const Piece8& P8) {
+  const uint32_t n = q.n;
+  const uint32_t od = tri_off(n, d) + i;
+  const float qb_ij = q.m[M_QB][od];
+  if (uni(__float_as_uint(qb_ij)) == 0xFF800000u) return;  // no pair (CONTRAfold), uniform
+  float p = q.m[M_P][od];  // the 2-loop half parked by outside_pair_head
+  const float qa_ij = q.m[M_QA][od];
+  const float sa = CONTRA ? qa_ij + b.params->contra.multibranch_score_basepair
+                          : qa_ij + b.params->turner.coeff_num_branches;
+  const float mun = CONTRA ? b.params->contra.multibranch_score_unpair : 0.f;
+  const uint32_t j = i + d;
+  const uint32_t lane = threadIdx.x & 63u;
+  // column j of {probs_multibranch, probs_multibranch2}; column i-1 of sums_1ormore, one row
+  // up: x_k = sums_1ormore_basepairs[k+1][i-1], the empty interval (-inf) for k = i-1
+  const float2* __restrict__ yycol = reinterpret_cast<const float2*>(q.m[M_PM]) + col_off(j);
+  const float* __restrict__ xcol = q.m[M_Q1C] + col_off(i >= 1 ? i - 1 : 0);
+  const uint32_t full = i >= 1 ? i - 1 : 0;  // steps k < full have all three terms
+  struct TBuf {
+    float x;
+    float2 yy;
+  };
+  // whole blocks of 64; a read past the cell's own rows stays inside the padded matrices
+  // (always-fetch form: the number of loads in flight at the wait is static, so the wait for
+  // this block's operands leaves the next block's loads in flight)
+  (void)pingpong<TBuf, 64, true>(
+      0u, (full + 63u) / 64u,
+      [&](TBuf& B, uint32_t k0) {
+        B.x = xcol[k0 + lane];
+        B.yy = yycol[k0 + lane];
+      },
+      [&](const TBuf& B, uint32_t k0) {
+        const uint32_t cnt = min(64u, full - k0);
+        const float bx = pin(B.x), by = pin(B.yy.x), by2 = pin(B.yy.y);
+        for (uint32_t l = 0; l < cnt; l++) {
+          const float x = lane_val(bx, l), y = lane_val(by, l), y2 = lane_val(by2, l);
+          p = lse_u(p, sa + y2 + x, P8);
+          p = lse_u(p, CONTRA ? sa + y + mun * static_cast<float>(i - (k0 + l) - 1) : sa + y, P8);
+          p = lse_u(p, sa + x + y, P8);
+        }
+      });
+  if (i >= 1) {
+    // k = i - 1: the interval [k+1, i-1] is empty, only the middle term exists
+    const float2 yy = yycol[i - 1];
+    p = lse_u(p, CONTRA ? sa + yy.x + mun * 0.f : sa + yy.x, P8);
+  }
+  if (lane == 0u && p > kNegInf) {
+    q.m[M_P][od] = p;
+    q.m[M_W][od] = p + q.m[M_MBC][od] - qb_ij;  // dense: read by outside_mb_lat
+  }
+}
+
+#endif  // RNAMC_LATENCY_H

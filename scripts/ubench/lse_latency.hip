@@ -116,6 +116,24 @@ __device__ __forceinline__ float lseE(float sum, float x, const PieceRegs& P) {
   const bool need_alt = (lo == kNegInf) || (z >= 11.862479f);
   return need_alt ? alt : __uint_as_float(v);
 }
+// F: one chain per WAVE (every lane holds the same sum): the identity piece (z >= 11.862479,
+// both operands finite) is a scalar branch away; otherwise E.  FL: the same with the branch
+// marked likely (fast path falls through).
+template <bool LIKELY>
+__device__ __forceinline__ float lseF(float sum, float x, const PieceRegs& P) {
+  float hi = vmax(sum, x), lo = vmin(sum, x), z = hi - lo;
+  const bool far = (__float_as_uint(z) - 0x413DCCB7u) < (0x7F800000u - 0x413DCCB7u);
+  const bool all_far = __ballot(far) != 0ull;
+  if (LIKELY ? __builtin_expect(all_far, 1) : all_far) return lo + z;
+  float r = ((P.c0 * z + P.c1) * z + P.c2) * z + P.c3;
+  r = lo + r;
+  const bool sel = (z >= P.tlo) && (z < P.thi);
+  unsigned v = sel ? __float_as_uint(r) : 0u;
+  v = dpp_or<0xB1>(v);
+  v = dpp_or<0x4E>(v);
+  v = dpp_or<0x141>(v);
+  return (z < 11.862479f) ? __uint_as_float(v) : hi;
+}
 template <int V, int CH>
 __global__ void __launch_bounds__(64) k(float* out, unsigned long long* cyc, int iters) {
   __shared__ Tab tab;
@@ -124,6 +142,10 @@ __global__ void __launch_bounds__(64) k(float* out, unsigned long long* cyc, int
   for (int c = 0; c < CH; c++) s[c] = threadIdx.x * 0.01f + c;
   float x = 0.3f + threadIdx.x * 0.001f;
   PieceRegs PR = piece_regs();
+  if (V >= 5) {  // one chain per wave; V 5/6: every step far (x = sum - 20), V 7: every step near
+    for (int c = 0; c < CH; c++) s[c] = 100.f + c;
+    x = (V == 7) ? 99.f : 60.f;
+  }
   if (V == 4) {  // a chain lives on 8 lanes: same operands on all of them
     for (int c = 0; c < CH; c++) s[c] = (threadIdx.x >> 3) * 0.08f + c;
     x = 0.3f + (threadIdx.x >> 3) * 0.008f;
@@ -140,6 +162,9 @@ __global__ void __launch_bounds__(64) k(float* out, unsigned long long* cyc, int
         if (V == 2) s[c] = lseC(s[c], xx, &tab);
         if (V == 3) s[c] = lseD(s[c], xx, &tab);
         if (V == 4) s[c] = lseE(s[c], xx, PR);
+        if (V == 5) s[c] = lseF<false>(s[c], xx, PR);
+        if (V == 6) s[c] = lseF<true>(s[c], xx, PR);
+        if (V == 7) s[c] = lseF<true>(s[c], xx, PR);
       }
     }
     x += 0.001f;
@@ -172,7 +197,30 @@ void run(const char* name) {
   printf("\n");
   hipFree(out); hipFree(cyc);
 }
+// does a launch that leaves most SIMDs idle run its waves at the same rate? (a lone long
+// sequence keeps 200-1500 chains going on 1024 SIMDs)
+template <int V>
+void sparse(const char* name) {
+  float* out; unsigned long long* cyc;
+  hipMalloc(&out, 4 * 64 * 65536); hipMalloc(&cyc, 8 * 65536);
+  const int iters = 2000;
+  printf("%-34s", name);
+  for (int blocks : {16, 64, 192, 512, 1024}) {
+    hipLaunchKernelGGL((k<V, 1>), dim3(blocks), dim3(64), 0, 0, out, cyc, 10);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k<V, 1>), dim3(blocks), dim3(64), 0, 0, out, cyc, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("  %4d waves: %6.2f ns/lse", blocks, ms * 1e6 / ((double)iters * 8));
+  }
+  printf("\n");
+  hipFree(out); hipFree(cyc);
+}
 int main() {
+  sparse<6>("FL all far, sparse launches");
+  sparse<0>("A cell-LUT, sparse launches");
   run<0, 1>("A cell-LUT        1 chain");
   run<1, 1>("B ladder+LDS coef 1 chain");
   run<2, 1>("C all-VALU        1 chain");
@@ -187,6 +235,10 @@ int main() {
   run<4, 1>("E 8-lane speculative 1 chain");
   run<4, 2>("E 8-lane speculative 2 chains");
   run<4, 3>("E 8-lane speculative 3 chains");
+  run<5, 1>("F wave-uniform, all far      ");
+  run<6, 1>("FL same, branch likely       ");
+  run<7, 1>("FL wave-uniform, all near    ");
+  run<6, 3>("FL all far, 3 sequential     ");
   run<0, 6>("A cell-LUT        6 chains");
   run<2, 6>("C all-VALU        6 chains");
   return 0;

@@ -616,3 +616,41 @@ def test_long_sequence_invariants(ctx):
     vals = m[m >= -0.5]
     assert vals.min() >= -0.001 and vals.max() < 1.001
     assert rowsum.max() < 1.01
+
+
+@pytest.mark.parametrize("contra,short", [(False, False), (True, False), (True, True)])
+def test_latency_forms_bit_exact(params, contra, short):
+    """Groups too small to fill the chip run the folds in their latency forms
+    (rnamc_latency.h): every chain on a group of 8 lanes, the 8 cubic pieces of ln_exp_1p
+    evaluated speculatively, a 7-instruction step when all chains of a wave take the identity
+    piece.  Forced onto a ragged batch (several sequences per launch, lengths around the
+    wave and chunk sizes) and taken by default by a lone sequence: same bits as the oracle
+    and as the throughput forms."""
+    from rna_algos_amd.mccaskill_algo import Context
+    rng = np.random.default_rng(277 + int(contra) + 2 * int(short))
+    lens = [1, 2, 4, 5, 6, 7, 8, 9, 15, 16, 17, 31, 33, 63, 64, 65, 100, 129, 200, 257, 300]
+    seqs = [rng.integers(0, 4, int(n)).astype(np.uint8) for n in lens]
+    seqs += [np.tile(np.array([2, 1], np.uint8), 40), np.zeros(50, np.uint8),
+             np.tile(np.array([2, 3, 3, 2, 1], np.uint8), 30)]
+    ctx = Context(params, device=0)
+    try:
+        ctx.set("latency_mode", 0)
+        base, logz0 = ctx.bpp_batch(seqs, contra, short)
+        ctx.set("latency_mode", 2)
+        lat, logz1 = ctx.bpp_batch(seqs, contra, short)
+        ctx.set("group_max_seqs", 5)  # several small groups
+        lat2, logz2 = ctx.bpp_batch(seqs, contra, short)
+        ctx.set("latency_mode", 1)    # default: a lone sequence takes the latency forms
+        one, logz3 = ctx.bpp_batch([seqs[-4]], contra, short)
+    finally:
+        ctx.close()
+    ref, ref_logz = O.bpp_batch(params.ptr, seqs, contra, short, n_threads=16)
+    for s, a, m, m2, r in zip(seqs, base, lat, lat2, ref):
+        for got in (m, m2):
+            assert np.array_equal(np.asarray(a.packed).view(np.uint32),
+                                  np.asarray(got.packed).view(np.uint32)), f"n={len(s)}"
+        assert_same(m.packed, r, f"n={len(s)}")
+    for lz in (logz0, logz1, logz2):
+        assert np.array_equal(np.asarray(lz).view(np.uint32), np.asarray(ref_logz).view(np.uint32))
+    assert_same(one[0].packed, ref[-4], "lone sequence")
+    assert np.float32(logz3[0]).view(np.uint32) == np.float32(ref_logz[-4]).view(np.uint32)
