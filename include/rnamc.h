@@ -313,6 +313,45 @@ int rnamc_centroid_fold(const float* bpp_packed, uint32_t n, float centroid_thre
                         uint32_t* pairs_out, uint32_t max_pairs, uint32_t* n_pairs,
                         float* expect_accuracy);
 
+/* ------------------------------------------------------------------------- */
+/* Durbin pair-HMM nucleotide match probabilities (SURVEY.md 8f-4;
+ * reference: src/durbin_algo.rs:73-264, constants src/compiled_align_scores.rs). */
+
+/* AlignScores (src/durbin_algo.rs:4-14). */
+typedef struct rnamc_align_scores {
+  float match2match_score;
+  float match2insert_score;
+  float insert_extend_score;
+  float insert_switch_score;
+  float init_match_score;
+  float init_insert_score;
+  float insert_scores[RNAMC_NUM_BASES];
+  float match_scores[RNAMC_NUM_BASES][RNAMC_NUM_BASES];
+} rnamc_align_scores;
+
+/* AlignScores::new(init_val) (src/durbin_algo.rs:26-40). */
+int rnamc_align_scores_new(float init_val, rnamc_align_scores* out);
+/* AlignScores::transfer (src/durbin_algo.rs:42-57): the compiled CONTRAlign constants of
+ * src/compiled_align_scores.rs:2-19 (they are part of the reference tree, unlike the
+ * McCaskill tables). */
+int rnamc_align_scores_transfer(rnamc_align_scores* scores);
+
+/* durbin_algo (src/durbin_algo.rs:73-77) over a batch of sequence pairs, as
+ * src/bin/durbin_algo.rs:55-75 runs one pool task per pair.
+ *   bases     concatenated codes of ALL sequences, each carrying PSEUDO_BASE (= 4,
+ *             src/utils.rs:122) at both ends as the reference's callers build them
+ *             (src/bin/durbin_algo.rs:49-51); real bases are codes 0..3
+ *   offsets   n_seqs+1 prefix offsets into `bases` (every sequence has length >= 2)
+ *   pair_a/b  n_pairs indices into the sequences: pair p aligns pair_a[p] with pair_b[p]
+ *   match_probs  per pair p a dense row-major ProbMat of len(a) x len(b) f32 at
+ *             match_probs + out_offsets[p] (border rows / columns are 0, as in the reference)
+ * Each pair's forward and backward sweeps run by anti-diagonal on the GPU; every logsumexp
+ * fold is the reference's, in its order. */
+int rnamc_durbin_batch(rnamc_ctx* ctx, const rnamc_align_scores* scores, uint32_t n_seqs,
+                       const uint8_t* bases, const uint64_t* offsets, uint32_t n_pairs,
+                       const uint32_t* pair_a, const uint32_t* pair_b, float* match_probs,
+                       const uint64_t* out_offsets);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,7 @@ SYMBOLS = [
     "rnamc_ctx_create", "rnamc_ctx_destroy", "rnamc_ctx_set", "rnamc_ctx_set_params",
     "rnamc_bpp_batch", "rnamc_bpp_batch_device", "rnamc_ctx_last_stats",
     "rnamc_debug_fetch", "rnamc_fold_scores", "rnamc_centroid_fold",
+    "rnamc_align_scores_new", "rnamc_align_scores_transfer", "rnamc_durbin_batch",
 ]
 
 
@@ -97,6 +98,9 @@ def lib():
     L.rnamc_fold_scores.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, vp, vp, vp, vp,
                                     C.c_uint64, u64p]
     L.rnamc_centroid_fold.argtypes = [vp, C.c_uint32, C.c_float, vp, C.c_uint32, u32p, f32p]
+    L.rnamc_align_scores_new.argtypes = [C.c_float, vp]
+    L.rnamc_align_scores_transfer.argtypes = [vp]
+    L.rnamc_durbin_batch.argtypes = [vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, vp, vp, vp]
     _lib = L
     return L
 

@@ -1143,4 +1143,101 @@ int rnamc_fold_scores(rnamc_ctx* c, const uint8_t* bases, uint32_t n, int uses_c
   return RNAMC_OK;
 }
 
+int rnamc_durbin_batch(rnamc_ctx* c, const rnamc_align_scores* scores, uint32_t n_seqs,
+                       const uint8_t* bases, const uint64_t* offsets, uint32_t n_pairs,
+                       const uint32_t* pair_a, const uint32_t* pair_b, float* match_probs,
+                       const uint64_t* out_offsets) {
+  if (!c || !scores || !offsets || (n_seqs && !bases) ||
+      (n_pairs && (!pair_a || !pair_b || !match_probs || !out_offsets)))
+    return RNAMC_ERR_INVALID_ARG;
+  if (n_pairs == 0) return RNAMC_OK;
+  for (uint32_t s = 0; s < n_seqs; s++) {
+    if (offsets[s + 1] < offsets[s]) return RNAMC_ERR_INVALID_ARG;
+    const uint64_t n = offsets[s + 1] - offsets[s];
+    // (the reference indexes [seq_len - 2]: a sequence is at least its two pseudo bases)
+    if (n < 2) return RNAMC_ERR_EMPTY_SEQ;
+    if (n > RNAMC_MAX_SEQ_LEN + 2ull) return RNAMC_ERR_SEQ_TOO_LONG;
+    // real bases inside, anything (PSEUDO_BASE) at the two ends, which are never scored
+    for (uint64_t x = offsets[s] + 1; x + 1 < offsets[s + 1]; x++)
+      if (bases[x] > 3) return RNAMC_ERR_INVALID_BASE;
+  }
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  DeviceGuard guard(c->device);
+  if (!guard.ok) return RNAMC_ERR_NO_DEVICE;
+  hipStream_t st = c->own_stream;
+  const uint64_t base_lo = offsets[0], base_hi = offsets[n_seqs];
+  uint8_t* d_bases = nullptr;
+  DurbinPair* d_pairs = nullptr;
+  float* d_out = nullptr;
+  auto cleanup = [&]() {
+    (void)hipStreamSynchronize(st);
+    if (d_bases) (void)hipFree(d_bases);
+    if (d_pairs) (void)hipFree(d_pairs);
+    if (d_out) (void)hipFree(d_out);
+  };
+#define HIPCHK_D(expr)                                                     \
+  do {                                                                     \
+    hipError_t _e = (expr);                                                \
+    if (_e != hipSuccess) {                                                \
+      set_last_error(std::string(#expr) + ": " + hipGetErrorString(_e));   \
+      cleanup();                                                           \
+      return (_e == hipErrorOutOfMemory) ? RNAMC_ERR_OOM : RNAMC_ERR_HIP;  \
+    }                                                                      \
+  } while (0)
+  HIPCHK_D(hipMalloc(&d_bases, std::max<uint64_t>(base_hi - base_lo, 1)));
+  HIPCHK_D(hipMemcpyAsync(d_bases, bases + base_lo, base_hi - base_lo, hipMemcpyHostToDevice, st));
+  // pairs in chunks whose six matrices per pair fit the workspace budget
+  const uint64_t ws_cap = static_cast<uint64_t>(std::max<int64_t>(c->group_ws_bytes, 1)) / 4;
+  std::vector<DurbinPair> chunk;
+  for (uint32_t p0 = 0; p0 < n_pairs;) {
+    chunk.clear();
+    uint64_t ws = 0, out = 0;
+    uint32_t max_cells = 0, p = p0;
+    for (; p < n_pairs; p++) {
+      if (pair_a[p] >= n_seqs || pair_b[p] >= n_seqs) {
+        cleanup();
+        return RNAMC_ERR_INVALID_ARG;
+      }
+      DurbinPair dp{};
+      dp.n1 = static_cast<uint32_t>(offsets[pair_a[p] + 1] - offsets[pair_a[p]]);
+      dp.n2 = static_cast<uint32_t>(offsets[pair_b[p] + 1] - offsets[pair_b[p]]);
+      const uint64_t cells = static_cast<uint64_t>(dp.n1) * dp.n2;
+      if (!chunk.empty() && ws + 6 * cells > ws_cap) break;
+      dp.a_off = offsets[pair_a[p]] - base_lo;
+      dp.b_off = offsets[pair_b[p]] - base_lo;
+      dp.ws_off = ws;
+      dp.out_off = out;
+      chunk.push_back(dp);
+      ws += 6 * cells;
+      out += cells;
+      max_cells = static_cast<uint32_t>(std::min<uint64_t>(std::max<uint64_t>(max_cells, cells), 0xFFFFFFFFull));
+    }
+    int rc = ensure_ws(c, ws);
+    if (rc) {
+      cleanup();
+      return rc;
+    }
+    if (d_pairs) HIPCHK_D(hipFree(d_pairs));
+    d_pairs = nullptr;
+    if (d_out) HIPCHK_D(hipFree(d_out));
+    d_out = nullptr;
+    HIPCHK_D(hipMalloc(&d_pairs, chunk.size() * sizeof(DurbinPair)));
+    HIPCHK_D(hipMalloc(&d_out, out * sizeof(float)));
+    HIPCHK_D(hipMemcpyAsync(d_pairs, chunk.data(), chunk.size() * sizeof(DurbinPair),
+                            hipMemcpyHostToDevice, st));
+    launch_durbin(d_pairs, static_cast<uint32_t>(chunk.size()), max_cells, d_bases, c->d_ws, d_out,
+                  *scores, st);
+    HIPCHK_D(hipGetLastError());
+    for (size_t x = 0; x < chunk.size(); x++)
+      HIPCHK_D(hipMemcpyAsync(match_probs + out_offsets[p0 + x], d_out + chunk[x].out_off,
+                              static_cast<uint64_t>(chunk[x].n1) * chunk[x].n2 * sizeof(float),
+                              hipMemcpyDeviceToHost, st));
+    HIPCHK_D(hipStreamSynchronize(st));
+    p0 = p;
+  }
+#undef HIPCHK_D
+  cleanup();
+  return RNAMC_OK;
+}
+
 }  // extern "C"

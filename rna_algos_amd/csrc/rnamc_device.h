@@ -59,6 +59,16 @@ void launch_inside_lat(const DeviceBatch& b, bool contra, uint32_t d, uint32_t m
                        bool do_chains, bool do_combine, hipStream_t st);
 void launch_outside_lat(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
                         bool do_mb, bool do_tail, hipStream_t st);
+// Durbin pair-HMM (src/durbin_algo.rs:90-264): one pair of sequences
+struct DurbinPair {
+  uint32_t n1, n2;   // lengths including the two pseudo bases
+  uint64_t a_off, b_off;  // offsets of the two sequences in the bases buffer
+  uint64_t ws_off;   // float offset of this pair's six n1 x n2 matrices in the workspace
+  uint64_t out_off;  // float offset of this pair's ProbMat in the output
+};
+void launch_durbin(const DurbinPair* d_pairs, uint32_t n_pairs, uint32_t max_cells,
+                   const uint8_t* d_bases, float* ws, float* d_out, const rnamc_align_scores& sc,
+                   hipStream_t st);
 void launch_finalize(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, uint32_t dmin_out,
                      hipStream_t st);
 

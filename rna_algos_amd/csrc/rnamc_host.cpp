@@ -490,4 +490,42 @@ int rnamc_centroid_fold(const float* bpp_packed, uint32_t n, float centroid_thre
   return RNAMC_OK;
 }
 
+// AlignScores::new (src/durbin_algo.rs:26-40)
+int rnamc_align_scores_new(float init_val, rnamc_align_scores* out) {
+  if (!out) return RNAMC_ERR_INVALID_ARG;
+  out->match2match_score = out->match2insert_score = init_val;
+  out->insert_extend_score = out->insert_switch_score = init_val;
+  out->init_match_score = out->init_insert_score = init_val;
+  for (int x = 0; x < RNAMC_NUM_BASES; x++) {
+    out->insert_scores[x] = init_val;
+    for (int y = 0; y < RNAMC_NUM_BASES; y++) out->match_scores[x][y] = init_val;
+  }
+  return RNAMC_OK;
+}
+
+// AlignScores::transfer (src/durbin_algo.rs:42-57).  The values are the generated CONTRAlign
+// constants of the reference's src/compiled_align_scores.rs:2-19 (data, f32 like `Prob`).
+int rnamc_align_scores_transfer(rnamc_align_scores* s) {
+  if (!s) return RNAMC_ERR_INVALID_ARG;
+  static const float kMatch[4][4] = {
+      {0.5256508867f, -0.40906402f, -0.2502759109f, -0.3252306723f},
+      {-0.40906402f, 0.6665219366f, -0.3289391181f, -0.1326088918f},
+      {-0.2502759109f, -0.3289391181f, 0.6684676551f, -0.3565888168f},
+      {-0.3252306723f, -0.1326088918f, -0.3565888168f, 0.459052045f},
+  };
+  static const float kInsert[4] = {-0.002521927159f, -0.08313891561f, -0.07443970653f,
+                                   -0.01290054598f};
+  s->match2match_score = 2.50575671f;
+  s->match2insert_score = 0.1970448791f;
+  s->insert_extend_score = 1.014026583f;
+  s->insert_switch_score = -7.346968782f;
+  s->init_match_score = 0.3959924457f;
+  s->init_insert_score = -0.3488104904f;
+  for (int x = 0; x < 4; x++) {
+    s->insert_scores[x] = kInsert[x];
+    for (int y = 0; y < 4; y++) s->match_scores[x][y] = kMatch[x][y];
+  }
+  return RNAMC_OK;
+}
+
 }  // extern "C"

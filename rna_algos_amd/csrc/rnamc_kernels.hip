@@ -1538,6 +1538,144 @@ __global__ void __launch_bounds__(64) k_outside_lat(DeviceBatch b, uint32_t d, u
   }
 }
 
+// ----------------------------------------------------------------------------
+// Durbin pair-HMM (src/durbin_algo.rs:90-264): forward and backward sums of one sequence
+// pair by anti-diagonal (cell (i,j) needs (i-1,j-1), (i-1,j), (i,j-1) resp. the +1
+// neighbours), one workgroup per (pair, direction), lanes = cells of the diagonal; then the
+// match probabilities, one lane per cell.  Six row-major n1 x n2 matrices per pair in the
+// workspace.  Every logsumexp fold has the reference's terms in the reference's order.
+constexpr uint32_t kDurbinThreads = 1024;
+
+__global__ void __launch_bounds__(kDurbinThreads)
+    k_durbin_sums(const DurbinPair* __restrict__ pairs, const uint8_t* __restrict__ bases,
+                  float* __restrict__ ws, rnamc_align_scores sc) {
+  __shared__ LseTab tabs;
+  load_lse_table(&tabs);
+  const LseTab* tab = &tabs;
+  const DurbinPair pr = pairs[blockIdx.x >> 1];
+  const bool backward = (blockIdx.x & 1u) != 0u;
+  const uint32_t n1 = pr.n1, n2 = pr.n2;
+  const uint8_t* __restrict__ a = bases + pr.a_off;
+  const uint8_t* __restrict__ b = bases + pr.b_off;
+  const size_t cells = static_cast<size_t>(n1) * n2;
+  float* __restrict__ m = ws + pr.ws_off + (backward ? 3 * cells : 0);
+  float* __restrict__ mi = m + cells;
+  float* __restrict__ md = m + 2 * cells;
+  // AlignSums::new (60-71)
+  for (size_t x = threadIdx.x; x < 3 * cells; x += blockDim.x) m[x] = kNegInf;
+  __syncthreads();
+  auto at = [n2](float* p, uint32_t i, uint32_t j) -> float& { return p[static_cast<size_t>(i) * n2 + j]; };
+  if (!backward) {
+    // cells 0 <= i <= n1-2, 0 <= j <= n2-2 (92-93), diagonal s = i + j
+    for (uint32_t s = 0; s + 4 <= n1 + n2; s++) {
+      const uint32_t ilo = s > n2 - 2 ? s - (n2 - 2) : 0u, ihi = min(s, n1 - 2);
+      for (uint32_t i = ilo + threadIdx.x; i <= ihi; i += blockDim.x) {
+        const uint32_t j = s - i;
+        if (i == 0 && j == 0) {
+          at(m, 0, 0) = 0.f;
+          continue;
+        }
+        if (i > 0 && j > 0) {
+          float sum = kNegInf;
+          const bool begins = (i - 1 == 0) && (j - 1 == 0);
+          sum = lse(sum, at(m, i - 1, j - 1) + (begins ? sc.init_match_score : sc.match2match_score), tab);
+          sum = lse(sum, at(mi, i - 1, j - 1) + sc.match2insert_score, tab);
+          sum = lse(sum, at(md, i - 1, j - 1) + sc.match2insert_score, tab);
+          at(m, i, j) = sum + sc.match_scores[a[i]][b[j]];
+        }
+        if (i > 0) {
+          float sum = kNegInf;
+          const bool begins = (i - 1 == 0) && (j == 0);
+          sum = lse(sum, at(m, i - 1, j) + (begins ? sc.init_insert_score : sc.match2insert_score), tab);
+          sum = lse(sum, at(mi, i - 1, j) + sc.insert_extend_score, tab);
+          at(mi, i, j) = sum + sc.insert_scores[a[i]];
+        }
+        if (j > 0) {
+          float sum = kNegInf;
+          const bool begins = (i == 0) && (j - 1 == 0);
+          sum = lse(sum, at(m, i, j - 1) + (begins ? sc.init_insert_score : sc.match2insert_score), tab);
+          sum = lse(sum, at(md, i, j - 1) + sc.insert_extend_score, tab);
+          at(md, i, j) = sum + sc.insert_scores[b[j]];
+        }
+      }
+      __syncthreads();
+    }
+  } else {
+    // cells 1 <= i <= n1-1, 1 <= j <= n2-1 (152-153), diagonal s = i + j descending
+    for (uint32_t s = n1 + n2 - 2; s >= 2; s--) {
+      const uint32_t ilo = s > n2 - 1 ? s - (n2 - 1) : 1u, ihi = min(s - 1, n1 - 1);
+      for (uint32_t i = ilo + threadIdx.x; i <= ihi; i += blockDim.x) {
+        const uint32_t j = s - i;
+        if (i == n1 - 1 && j == n2 - 1) {
+          at(m, i, j) = 0.f;
+          continue;
+        }
+        if (i < n1 - 1 && j < n2 - 1) {
+          float sum = kNegInf;
+          const bool ends = (i + 1 == n1 - 1) && (j + 1 == n2 - 1);
+          sum = lse(sum, at(m, i + 1, j + 1) + (ends ? 0.f : sc.match2match_score), tab);
+          sum = lse(sum, at(mi, i + 1, j + 1) + sc.match2insert_score, tab);
+          sum = lse(sum, at(md, i + 1, j + 1) + sc.match2insert_score, tab);
+          at(m, i, j) = sum + sc.match_scores[a[i]][b[j]];
+        }
+        if (i < n1 - 1) {
+          float sum = kNegInf;
+          const bool ends = (i + 1 == n1 - 1) && (j == n2 - 1);
+          sum = lse(sum, at(m, i + 1, j) + (ends ? 0.f : sc.match2insert_score), tab);
+          sum = lse(sum, at(mi, i + 1, j) + sc.insert_extend_score, tab);
+          at(mi, i, j) = sum + sc.insert_scores[a[i]];
+        }
+        if (j < n2 - 1) {
+          float sum = kNegInf;
+          const bool ends = (i == n1 - 1) && (j + 1 == n2 - 1);
+          sum = lse(sum, at(m, i, j + 1) + (ends ? 0.f : sc.match2insert_score), tab);
+          sum = lse(sum, at(md, i, j + 1) + sc.insert_extend_score, tab);
+          at(md, i, j) = sum + sc.insert_scores[b[j]];
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// get_match_probs (src/durbin_algo.rs:217-264)
+__global__ void __launch_bounds__(256)
+    k_durbin_probs(const DurbinPair* __restrict__ pairs, const float* __restrict__ ws,
+                   float* __restrict__ out, rnamc_align_scores sc) {
+  __shared__ LseTab tabs;
+  load_lse_table(&tabs);
+  const LseTab* tab = &tabs;
+  const DurbinPair pr = pairs[blockIdx.y];
+  const uint32_t n1 = pr.n1, n2 = pr.n2;
+  const size_t cells = static_cast<size_t>(n1) * n2;
+  const float* fm = ws + pr.ws_off;
+  const float* fi = fm + cells;
+  const float* fd = fm + 2 * cells;
+  const float* bm = fm + 3 * cells;
+  const float* bi = fm + 4 * cells;
+  const float* bd = fm + 5 * cells;
+  float* probs = out + pr.out_off;
+  const size_t last = static_cast<size_t>(n1 - 2) * n2 + (n2 - 2);
+  float global_sum = fm[last];
+  global_sum = lse(global_sum, fi[last], tab);
+  global_sum = lse(global_sum, fd[last], tab);
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t x = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; x < cells; x += stride) {
+    const uint32_t i = static_cast<uint32_t>(x / n2), j = static_cast<uint32_t>(x - static_cast<size_t>(i) * n2);
+    float p = 0.f;
+    if (i >= 1 && i + 1 < n1 && j >= 1 && j + 1 < n2) {
+      const size_t nx = static_cast<size_t>(i + 1) * n2 + (j + 1);
+      const bool ends = (i + 1 == n1 - 1) && (j + 1 == n2 - 1);
+      float sum = kNegInf;
+      sum = lse(sum, (ends ? 0.f : sc.match2match_score) + bm[nx], tab);
+      sum = lse(sum, sc.match2insert_score + bi[nx], tab);
+      sum = lse(sum, sc.match2insert_score + bd[nx], tab);
+      p = expf_ref(fm[x] + sum - global_sum);
+    }
+    probs[x] = p;
+  }
+}
+
 // final map (src/mccaskill_algo.rs:608 / 721) + log partition function.  A pair is
 // in the reference's SparseProbMat iff it got a probability, i.e. iff it is in
 // sums_close and its span was visited by the outside sweep (602-604 / 715-717).
@@ -1711,6 +1849,16 @@ void launch_outside_lat(const DeviceBatch& b, bool contra, uint32_t d, uint32_t 
   } else {
     hipLaunchKernelGGL(k_outside_lat<false>, g, dim3(64), lds_cap, st, b, d, cells, nseq, a0, a1);
   }
+}
+
+void launch_durbin(const DurbinPair* d_pairs, uint32_t n_pairs, uint32_t max_cells,
+                   const uint8_t* d_bases, float* ws, float* d_out, const rnamc_align_scores& sc,
+                   hipStream_t st) {
+  if (n_pairs == 0) return;
+  hipLaunchKernelGGL(k_durbin_sums, dim3(2 * n_pairs), dim3(kDurbinThreads), 0, st, d_pairs, d_bases,
+                     ws, sc);
+  const uint32_t gx = std::max<uint32_t>(1u, std::min<uint32_t>((max_cells + 255u) / 256u, 256u));
+  hipLaunchKernelGGL(k_durbin_probs, dim3(gx, n_pairs), dim3(256), 0, st, d_pairs, ws, d_out, sc);
 }
 
 // LDS bytes of one k_head workgroup: tables + 31 window rows of (wmax + 32) elements

@@ -33,6 +33,7 @@ def lib():
         L.rnamc_oracle_free.argtypes = [vp]
         L.rnamc_oracle_free.restype = None
         L.rnamc_oracle_centroid_fold.argtypes = [vp, C.c_uint32, C.c_float, vp, C.c_uint32, vp, vp]
+        L.rnamc_oracle_durbin.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, vp]
         _lib = L
     return _lib
 
@@ -128,6 +129,16 @@ def centroid_fold(packed, n, gamma):
                                           pairs.ctypes.data, pairs.shape[0], C.byref(npairs),
                                           C.byref(acc)))
     return [(int(a), int(b)) for a, b in pairs[:npairs.value]], float(acc.value)
+
+
+def durbin(scores_ptr, a, b):
+    """match probabilities of one pair (sequences WITH pseudo bases) -> f32[len(a), len(b)]"""
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    out = np.empty((len(a), len(b)), dtype=np.float32)
+    _chk(lib().rnamc_oracle_durbin(scores_ptr, a.ctypes.data, len(a), b.ctypes.data, len(b),
+                                   out.ctypes.data))
+    return out
 
 
 def splitmix_seq(n, seed):
