@@ -16,7 +16,8 @@ HEADER = os.path.join(ROOT, "include", "rnamc.h")
 # opaque / struct pointees that correspond across the boundary
 OPAQUE = {"rnamc_ctx": "ctx", "RnamcCtx": "ctx", "rnamc_params": "void", "c_void": "void",
           "void": "void", "rnamc_twoloop_score": "twoloop", "TwoloopScore": "twoloop",
-          "rnamc_fold_score_sets": "void", "rnamc_batch_stats": "stats"}
+          "rnamc_fold_score_sets": "void", "rnamc_batch_stats": "stats",
+          "rnamc_align_scores": "align", "AlignScoresC": "align"}
 C_SCALAR = {"int": "i32", "uint32_t": "u32", "uint64_t": "u64", "int64_t": "i64", "float": "f32",
             "size_t": "usize", "uint8_t": "u8", "char": "i8", "double": "f64"}
 R_SCALAR = {"c_int": "i32", "u32": "u32", "u64": "u64", "i64": "i64", "f32": "f32",
@@ -81,8 +82,11 @@ def c_decls():
     return decls
 
 
-def rust_decls():
-    src = open(SHIM).read()
+DURBIN_SHIM = os.path.join(ROOT, "bindings", "rust", "durbin_algo.rs")
+
+
+def rust_decls(path=SHIM):
+    src = open(path).read()
     src = re.sub(r"//[^\n]*", "", src)
     block = re.search(r'extern "C" \{(.*?)\n\}', src, flags=re.S).group(1)
     decls = {}
@@ -105,6 +109,26 @@ def test_extern_block_matches_header():
         assert len(params) == len(cparams), f"{name}: arity {len(params)} vs C {len(cparams)}"
         for k, (a, b) in enumerate(zip(params, cparams)):
             assert normalise(a) == normalise(b), f"{name}: parameter {k}: Rust {a} vs C {b}"
+
+
+def test_durbin_extern_block_matches_header():
+    c, r = c_decls(), rust_decls(DURBIN_SHIM)
+    assert "rnamc_durbin_batch" in r
+    for name, (ret, params) in r.items():
+        assert name in c, f"{name} is not declared in include/rnamc.h"
+        cret, cparams = c[name]
+        assert normalise(ret) == normalise(cret), name
+        assert len(params) == len(cparams), name
+        for k, (a, b) in enumerate(zip(params, cparams)):
+            assert normalise(a) == normalise(b), f"{name}: parameter {k}: Rust {a} vs C {b}"
+    # the #[repr(C)] mirror of rnamc_align_scores: same fields, same order
+    src = open(DURBIN_SHIM).read()
+    body = re.search(r"pub struct AlignScoresC \{(.*?)\n\}", src, flags=re.S).group(1)
+    rust_fields = [f.split(":")[0].strip() for f in body.split("\n") if ":" in f]
+    hdr = re.sub(r"/\*.*?\*/", " ", open(HEADER).read(), flags=re.S)
+    cbody = re.search(r"typedef struct rnamc_align_scores \{(.*?)\}", hdr, flags=re.S).group(1)
+    c_fields = [re.sub(r"\[.*", "", f.split()[-1]) for f in cbody.split(";") if f.strip()]
+    assert rust_fields == c_fields
 
 
 def test_header_symbols_are_exported_and_bound():
