@@ -85,7 +85,12 @@ struct rnamc_ctx {
   // group's longest diagonal holds at most lat_max_cells cells over all its sequences, 2 always
   int64_t latency_mode = 1;
   int64_t lat_max_cells = 16384;
-  int64_t lat_inside = 0;  // the inside sweep of such a group takes its wave-per-chain form too
+  // optional (off: measured equal to the three-lanes-per-cell form for Turner, 5 % faster for
+  // CONTRAfold): the inside folds of such a group run one wave per chain on the diagonals whose
+  // launches hold at most lat_inside_waves chains (3 per cell)
+  int64_t lat_inside = 0;
+  int64_t lat_inside_waves = 2048;
+  int64_t lat_pairs = 1;   // its 2-loop blocks run one wave per listed cell (both sweeps)
   int64_t head_wmax_in = 448, head_wmax_out = 448;
   // role mask of timing experiments (bit0 folds, 1 pair block, 2 mb, 3 pair probs); settable
   // only in builds with -DRNAMC_DEBUG_KNOBS (make DEBUG_KNOBS=1), constant 15 otherwise
@@ -361,9 +366,9 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
     const bool lat = c->latency_mode == 2 ||
                      (c->latency_mode == 1 &&
                       static_cast<uint64_t>(nseq) * gmax <= static_cast<uint64_t>(c->lat_max_cells));
-    const bool lat_in = lat && c->lat_inside != 0;
+    const bool lat_in = lat && (c->lat_inside != 0 || c->lat_pairs != 0);
     if (lat_in) {
-      bool have_a = false, have_b = false;
+      bool have_a = false, have_b = false, combine_due = false;
       for (uint32_t d = dmin_in; d < gmax; d++) {
         need_pairs(d);  // (only the first diagonal finds work here)
         const bool pair_next = heads_done < static_cast<int64_t>(d) + 1 && d + 1 < gmax;
@@ -374,14 +379,30 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
             have_a = true;
           }
           HIPCHK(hipStreamWaitEvent(c->aux_stream, c->ev_a[pv], 0));
-          launch_inside(b, contra, d, gmax, active(d + 1), block, false, true, c->aux_stream);
+          if (c->lat_pairs != 0) {
+            launch_pair_lat(b, contra, false, d + 1, gmax, active(d + 1), c->aux_stream);
+          } else {
+            launch_inside(b, contra, d, gmax, active(d + 1), block, false, true, c->aux_stream);
+          }
           c->stats.launches_inside++;
         }
         if (have_b) HIPCHK(hipStreamWaitEvent(st, c->ev_b[pv], 0));
         if (do_sums) {
-          // (the combine of diagonal d-1 rides along: sequences that end at d-1 included)
-          launch_inside_lat(b, contra, d, gmax, active(d >= 1 ? d - 1 : 0), true, d > dmin_in, st);
-          c->stats.launches_inside++;
+          // One wave per fold chain while the launch's 3 x cells chains leave every chain wave
+          // (nearly) a SIMD of its own, the three-lanes-per-cell form before that.  The
+          // wave-per-chain form completes sums_1ormore_basepairs of diagonal d-1 in the launch
+          // of diagonal d (sequences that end at d-1 included).
+          const uint64_t chains = 3ull * (gmax - d) * active(d);
+          const bool wave_form = c->lat_inside != 0 && chains <= static_cast<uint64_t>(c->lat_inside_waves);
+          if (wave_form || combine_due) {
+            launch_inside_lat(b, contra, d, gmax, active(d >= 1 ? d - 1 : 0), wave_form, combine_due, st);
+            c->stats.launches_inside++;
+          }
+          if (!wave_form) {
+            launch_inside(b, contra, d, gmax, active(d), block, true, false, st);
+            c->stats.launches_inside++;
+          }
+          combine_due = wave_form;
         }
         HIPCHK(hipEventRecord(c->ev_a[cu], st));
         have_a = true;
@@ -394,7 +415,7 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
         }
       }
       if (have_b) HIPCHK(hipStreamWaitEvent(st, c->ev_b[(gmax - 1) % ring], 0));
-      if (do_sums && gmax > dmin_in)  // combine of the last diagonal
+      if (combine_due)  // combine of the last diagonal
         launch_inside_lat(b, contra, gmax, gmax, active(gmax - 1), false, true, st);
     }
     for (uint32_t d = dmin_in; d < gmax && !lat_in;) {
@@ -496,7 +517,11 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
           HIPCHK(hipEventRecord(c->ev_a[cu], st));
           if (head && r_head) {
             timed(3, c->aux_stream, [&]() {
-              launch_outside(b, contra, d, gmax, na, block, false, false, true, 4, c->aux_stream);
+              if (c->lat_pairs != 0) {
+                launch_pair_lat(b, contra, true, d - 1, gmax, na, c->aux_stream);
+              } else {
+                launch_outside(b, contra, d, gmax, na, block, false, false, true, 4, c->aux_stream);
+              }
             });
             c->stats.launches_outside++;
           }
@@ -828,6 +853,10 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     c->lat_max_cells = value;
   } else if (k == "lat_inside") {
     c->lat_inside = value;
+  } else if (k == "lat_inside_waves" && value >= 0) {
+    c->lat_inside_waves = value;
+  } else if (k == "lat_pairs") {
+    c->lat_pairs = value;
   } else if ((k == "head_wmax_in" || k == "head_wmax_out") && value >= 64 && value <= 4096) {
     // the window must fit the CU's 160 KB of LDS beside the tables
     if (head_smem_bytes(k == "head_wmax_out", static_cast<uint32_t>(value)) > 160u * 1024u)

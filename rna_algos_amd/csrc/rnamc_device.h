@@ -59,6 +59,9 @@ void launch_inside_lat(const DeviceBatch& b, bool contra, uint32_t d, uint32_t m
                        bool do_chains, bool do_combine, hipStream_t st);
 void launch_outside_lat(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
                         bool do_mb, bool do_tail, hipStream_t st);
+// closing-pair block (inside) / 2-loop half of the pair probabilities (outside) of diagonal d
+void launch_pair_lat(const DeviceBatch& b, bool contra, bool outside, uint32_t d, uint32_t max_n,
+                     uint32_t nseq, hipStream_t st);
 // Durbin pair-HMM (src/durbin_algo.rs:90-264): one pair of sequences
 struct DurbinPair {
   uint32_t n1, n2;   // lengths including the two pseudo bases

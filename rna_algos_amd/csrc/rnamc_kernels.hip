@@ -1676,6 +1676,26 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// one wave per listed cell: closing-pair block of diagonal d (inside) / 2-loop half of the pair
+// probability of diagonal d (outside), rnamc_latency.h
+template <bool CONTRA, bool OUTSIDE>
+__global__ void __launch_bounds__(64) k_pair_lat(DeviceBatch b, uint32_t d, uint32_t nseq) {
+  const uint32_t bx = blockIdx.x / nseq;
+  const uint32_t which = blockIdx.x - bx * nseq;
+  const Seq q = load_seq(b, which);
+  const uint32_t n = q.n;
+  if (d >= n) return;
+  const uint32_t cnt = q.ccnt[d];
+  if (bx >= cnt) return;
+  const uint32_t i = uni(static_cast<uint32_t>(q.cidx[tri_off(n, d) + bx]));
+  const Piece8 P8 = load_piece8();
+  if (OUTSIDE) {
+    outside_head_lat<CONTRA>(b, q, d, i, P8);
+  } else {
+    inside_pair_lat<CONTRA, PAIR_FULL>(b, q, d, i, P8);
+  }
+}
+
 // final map (src/mccaskill_algo.rs:608 / 721) + log partition function.  A pair is
 // in the reference's SparseProbMat iff it got a probability, i.e. iff it is in
 // sums_close and its span was visited by the outside sweep (602-604 / 715-717).
@@ -1859,6 +1879,20 @@ void launch_durbin(const DurbinPair* d_pairs, uint32_t n_pairs, uint32_t max_cel
                      ws, sc);
   const uint32_t gx = std::max<uint32_t>(1u, std::min<uint32_t>((max_cells + 255u) / 256u, 256u));
   hipLaunchKernelGGL(k_durbin_probs, dim3(gx, n_pairs), dim3(256), 0, st, d_pairs, ws, d_out, sc);
+}
+
+// latency form of the 2-loop blocks: one wave per listed cell of diagonal d
+void launch_pair_lat(const DeviceBatch& b, bool contra, bool outside, uint32_t d, uint32_t max_n,
+                     uint32_t nseq, hipStream_t st) {
+  if (d >= max_n || nseq == 0) return;
+  const dim3 g((max_n - d) * nseq, 1, 1);
+  if (contra) {
+    if (outside) hipLaunchKernelGGL((k_pair_lat<true, true>), g, dim3(64), 0, st, b, d, nseq);
+    else hipLaunchKernelGGL((k_pair_lat<true, false>), g, dim3(64), 0, st, b, d, nseq);
+  } else {
+    if (outside) hipLaunchKernelGGL((k_pair_lat<false, true>), g, dim3(64), 0, st, b, d, nseq);
+    else hipLaunchKernelGGL((k_pair_lat<false, false>), g, dim3(64), 0, st, b, d, nseq);
+  }
 }
 
 // LDS bytes of one k_head workgroup: tables + 31 window rows of (wmax + 32) elements

@@ -86,7 +86,6 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) {
   return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v)));
 }
 
-constexpr int kULat = 16;  // fold steps per operand buffer (two buffers)
 
 // ----------------------------------------------------------------------------
 // inside: one wave per (cell, role) of diagonal d
@@ -100,10 +99,11 @@ __device__ __forceinline__ void inside_chain_lat(const DeviceBatch& b, const Seq
                                                  uint32_t i, uint32_t role, const Piece8& P8) {
   const uint32_t n = q.n;
   const uint32_t od = tri_off(n, d) + i;
+  const uint32_t lane = threadIdx.x & 63u;
   const float* __restrict__ zre = q.m[M_ZRE];
   const float* __restrict__ zrm = q.m[CONTRA ? M_ZRM : M_ZRE];
   const float* __restrict__ qa = q.m[M_QA];
-  const bool lane0 = (threadIdx.x & 63u) == 0u;
+  const bool lane0 = lane == 0u;
   float zr = kNegInf, c = 0.f, mun = 0.f;
   if (!CONTRA) {
     // sums_rightmost_basepairs_external(i,j) = that of (i,j-1) extended by one step (344-351)
@@ -114,26 +114,23 @@ __device__ __forceinline__ void inside_chain_lat(const DeviceBatch& b, const Seq
   } else {
     const rnamc_fold_score_sets& f = b.params->contra;
     mun = f.multibranch_score_unpair;
-    if (role < 2) {
-      // (468-486): x + P + Q * (j - k), (P, Q) = (ext_bp, ext_unpair) / (mb_bp, mb_unpair)
+    if (role < 2 && d >= 1) {
+      // (468-486): steps t = 1..d, k = i + t: x + P + Q * (j - k) with
+      // (P, Q) = (ext_bp, ext_unpair) / (mb_bp, mb_unpair); lane l loads step t0 + l
       const float Pc = (role == 0) ? f.external_score_basepair : f.multibranch_score_basepair;
       const float Qc = (role == 0) ? f.external_score_unpair : mun;
       struct ABuf {
-        float xs[kULat];
+        float x;
       };
-      uint32_t t = pingpong<ABuf, kULat>(
-          1u, d / kULat,
-          [&](ABuf& B, uint32_t t0) {
-#pragma unroll
-            for (int u = 0; u < kULat; u++) B.xs[u] = qa[tri_off(n, t0 + u) + i];
-          },
+      (void)pingpong<ABuf, 64, true>(
+          1u, (d + 63u) / 64u,
+          [&](ABuf& B, uint32_t t0) { B.x = qa[tri_off(n, min(t0 + lane, d)) + i]; },
           [&](const ABuf& B, uint32_t t0) {
-#pragma unroll
-            for (int u = 0; u < kULat; u++)
-              zr = lse_u(zr, B.xs[u] + Pc + Qc * static_cast<float>(d - t0 - u), P8);
+            const uint32_t cnt = min(64u, d + 1u - t0);
+            const float bx = pin(B.x);
+            for (uint32_t l = 0; l < cnt; l++)
+              zr = lse_u(zr, lane_val(bx, l) + Pc + Qc * static_cast<float>(d - t0 - l), P8);
           });
-      for (; t <= d; t++)
-        zr = lse_u(zr, qa[tri_off(n, t) + i] + Pc + Qc * static_cast<float>(d - t), P8);
       if (lane0) q.m[role == 0 ? M_ZRE : M_ZRM][od] = zr;
     }
   }
@@ -149,32 +146,34 @@ __device__ __forceinline__ void inside_chain_lat(const DeviceBatch& b, const Seq
   }
   const float* __restrict__ pa = (CONTRA && role != 0) ? zrm : zre;
   const float* __restrict__ pb = q.m[role == 0 ? M_Z : M_Q1D];
-  auto step = [&](float ra, float rb, uint32_t t) {
-    float term;
-    if (!CONTRA) {
-      term = (role == 0) ? ra + rb : (role == 1 ? ra + c : rb + (ra + c));
-    } else {
-      term = (role == 1) ? ra + mun * static_cast<float>(t) : rb + ra;
-    }
-    acc = lse_u(acc, term, P8);
-  };
-  struct SBuf {
-    float ra[kULat], rb[kULat];
-  };
-  uint32_t t = pingpong<SBuf, kULat>(
-      1u, d >= 1 ? (d - 1) / kULat : 0u,
-      [&](SBuf& B, uint32_t t0) {
-#pragma unroll
-        for (int u = 0; u < kULat; u++) {
-          B.ra[u] = pa[tri_off(n, d - t0 - u) + t0 + u + i];
-          B.rb[u] = pb[tri_off(n, t0 + u - 1) + i];
-        }
-      },
-      [&](const SBuf& B, uint32_t t0) {
-#pragma unroll
-        for (int u = 0; u < kULat; u++) step(B.ra[u], B.rb[u], t0 + u);
-      });
-  for (; t < d; t++) step(pa[tri_off(n, d - t) + t + i], pb[tri_off(n, t - 1) + i], t);
+  if (d >= 2) {
+    // steps t = 1 .. d-1; lane l loads the two operands of step t0 + l
+    struct SBuf {
+      float ra, rb;
+    };
+    (void)pingpong<SBuf, 64, true>(
+        1u, (d - 1u + 63u) / 64u,
+        [&](SBuf& B, uint32_t t0) {
+          const uint32_t t = min(t0 + lane, d - 1u);
+          B.ra = pa[tri_off(n, d - t) + t + i];
+          B.rb = pb[tri_off(n, t - 1u) + i];
+        },
+        [&](const SBuf& B, uint32_t t0) {
+          const uint32_t cnt = min(64u, d - t0);
+          const float bra = pin(B.ra), brb = pin(B.rb);
+          for (uint32_t l = 0; l < cnt; l++) {
+            const float ra = lane_val(bra, l);
+            float term;
+            if (!CONTRA) {
+              term = (role == 0) ? ra + lane_val(brb, l)
+                                 : (role == 1 ? ra + c : lane_val(brb, l) + (ra + c));
+            } else {
+              term = (role == 1) ? ra + mun * static_cast<float>(t0 + l) : lane_val(brb, l) + ra;
+            }
+            acc = lse_u(acc, term, P8);
+          }
+        });
+  }
   if (lane0) {
     if (role == 0) q.m[M_Z][od] = acc;
     if (role == 1) q.m[M_Q1D][od] = acc;  // parked: inside_combine_lat turns it into sums_1ormore
@@ -300,6 +299,117 @@ __device__ __forceinline__ void outside_tail_lat(const DeviceBatch& b, const Seq
     q.m[M_P][od] = p;
     q.m[M_W][od] = p + q.m[M_MBC][od] - qb_ij;  // dense: read by outside_mb_lat
   }
+}
+
+// ----------------------------------------------------------------------------
+// The 2-loop blocks of one listed cell per wave.  Lane b of the wave owns probe (a, b) of the
+// current row a: it loads that pair's operand(s) and scores the loop with the plain scorer of
+// rnamc_scoring.h (same expression trees as the table-driven one of rnamc_probes.h; this
+// is the scorer behind FoldScores) — 31 - a terms computed side by side — and the chain then
+// folds the row's PRESENT pairs in ascending b through a ballot, scalar bit scans and
+// v_readlane.  An absent pair is a map miss in the reference (no fold step at all).  The
+// next row's terms are computed before the current row is folded.
+template <bool CONTRA, int MODE>
+__device__ __forceinline__ void inside_pair_lat(const DeviceBatch& b, const Seq& q, uint32_t d,
+                                                uint32_t i, const Piece8& P8) {
+  const uint32_t n = q.n;
+  const uint32_t j = i + d;
+  const uint8_t* __restrict__ s = q.s;
+  const uint32_t lane = threadIdx.x & 63u;
+  if (!(b.allows_short_hairpins && CONTRA) && d + 1 < RNAMC_MIN_SPAN_HAIRPIN_CLOSE) return;
+  const auto model = ModelOf<CONTRA>::make(b);
+  const uint32_t o = tri_off(n, d) + i;
+  const float* __restrict__ qb = q.m[M_QB];
+  float sum = kNegInf;
+  if (!CONTRA || d - 1 <= RNAMC_MAX_LOOP_LEN) sum = lse_u(sum, model.hairpin(s, n, i, j), P8);
+  if (d >= 3) {
+    // enclosed pairs (k,l) = (i+1+a, j-1-bb), a ascending, bb ascending (l descending),
+    // a + bb <= 30, l > k  <=>  a + bb <= d-3
+    const uint32_t lim = min(static_cast<uint32_t>(RNAMC_MAX_2LOOP_LEN), d - 3);
+    auto row_term = [&](uint32_t a) {
+      float term = kNegInf;
+      if (a <= lim && lane <= lim - a) {
+        const uint32_t k = i + 1u + a, l = j - 1u - lane;
+        const float x = qb[tri_off(n, l - k) + k];
+        if (x > kNegInf) term = x + model.twoloop(s, i, j, k, l);
+      }
+      return term;
+    };
+    float cur = row_term(0u);
+    for (uint32_t a = 0; a <= lim; a++) {
+      const float nxt = row_term(a + 1u);  // (all -inf past the last row)
+      const float t = pin(cur);
+      unsigned long long m = __ballot(t > kNegInf);
+      while (m) {
+        const uint32_t l = static_cast<uint32_t>(__builtin_ctzll(m));
+        m &= m - 1ull;
+        sum = lse_u(sum, lane_val(t, l), P8);
+      }
+      cur = nxt;
+    }
+  }
+  const float mbc = model.mbclose(s, n, i, j);
+  const float qm = (d >= 2) ? q.m[M_QM][tri_off(n, d - 2) + i + 1] : kNegInf;
+  sum = lse_u(sum, qm + mbc, P8);
+  const float acc = model.accessible(s, n, i, j);
+  if (lane == 0u && sum > kNegInf) {
+    q.m[M_MBC][o] = mbc;
+    q.m[M_QB][o] = sum;
+    q.m[M_QA][o] = sum + acc;
+  }
+}
+
+// pair probability of one listed cell, first half: exterior term ⊕ enclosing 2-loops
+// (src/mccaskill_algo.rs:559-593 / 663-700); the running sum is parked in the log-prob slot
+// for outside_tail_lat.
+template <bool CONTRA>
+__device__ __forceinline__ void outside_head_lat(const DeviceBatch& b, const Seq& q, uint32_t d,
+                                                 uint32_t i, const Piece8& P8) {
+  const uint32_t n = q.n;
+  const uint32_t j = i + d;
+  const uint8_t* __restrict__ s = q.s;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t od = tri_off(n, d) + i;
+  const float* __restrict__ qb = q.m[M_QB];
+  const float* __restrict__ lp = q.m[M_P];
+  const float qb_ij = qb[od];
+  if (uni(__float_as_uint(qb_ij)) == 0xFF800000u) return;  // not in sums_close
+  const auto model = ModelOf<CONTRA>::make(b);
+  const float qa_ij = q.m[M_QA][od];
+  const float* z = q.m[M_Z];
+  const float ztot = z[tri_off(n, n - 1)];
+  const float zl = (i < 1) ? 0.f : z[tri_off(n, i - 1)];                  // Z[0][i-1]
+  const float zr = (j > n - 2) ? 0.f : z[tri_off(n, n - 2 - j) + j + 1];  // Z[j+1][n-1]
+  float p = CONTRA ? zl + zr + qa_ij + b.params->contra.external_score_basepair - ztot
+                   : zl + qa_ij + zr - ztot;
+  if (d + 2 < n) {
+    // enclosing pairs (k,l) = (i-1-a, j+1+bb), a ascending (k descending), bb ascending,
+    // a + bb <= 30, k >= 0, l <= n-1
+    const uint32_t lim = min(static_cast<uint32_t>(RNAMC_MAX_2LOOP_LEN), n - 3 - d);
+    auto row_term = [&](uint32_t a) {
+      float term = kNegInf;
+      if (a <= lim && a < i && lane <= lim - a && j + 1u + lane <= n - 1u) {
+        const uint32_t k = i - 1u - a, l = j + 1u + lane;
+        const uint32_t x = tri_off(n, l - k) + k;
+        const float qkl = qb[x];
+        if (qkl > kNegInf) term = lp[x] + qb_ij - qkl + model.twoloop(s, k, l, i, j);
+      }
+      return term;
+    };
+    float cur = row_term(0u);
+    for (uint32_t a = 0; a <= lim; a++) {
+      const float nxt = row_term(a + 1u);
+      const float t = pin(cur);
+      unsigned long long m = __ballot(t > kNegInf);
+      while (m) {
+        const uint32_t l = static_cast<uint32_t>(__builtin_ctzll(m));
+        m &= m - 1ull;
+        p = lse_u(p, lane_val(t, l), P8);
+      }
+      cur = nxt;
+    }
+  }
+  if (lane == 0u) q.m[M_P][od] = p;
 }
 
 #endif  // RNAMC_LATENCY_H
