@@ -174,9 +174,10 @@ def cpu_baseline(params, seqs, contra, budget_s):
         pick = np.argsort(np.abs(lens - n_target), kind="stable")[:cores]
         sample = [seqs[i] for i in pick]
     else:
-        # a single long sequence (n = 4096): every core times the same prefix whose cost fits
+        # fewer sequences than cores (a single long sequence): the reference folds one sequence
+        # on one thread, so one thread per sequence times a prefix whose cost fits the budget
         m = int(min(n_target, lens.min()))
-        sample = [seqs[int(np.argmin(lens))][:m]] * cores
+        sample = [s[:m] for s in seqs]
     t0 = time.time()
     O.bpp_batch(params.ptr, sample, contra, False, n_threads=len(sample), want_bpp=False)
     dt = time.time() - t0
@@ -457,9 +458,12 @@ def main():
     ms_in = ms_out = 0.0
     l_in = l_out = 0
     t0 = time.perf_counter()
+    step_s = []
     for _ in range(steps):
+        ts = time.perf_counter()
         step()
         st = ctx.stats()  # event-timed sweeps of this step (the call synchronised its stream)
+        step_s.append(time.perf_counter() - ts)
         ms_in += st["ms_inside"]
         ms_out += st["ms_outside"]
         l_in += st["launches_inside"]
@@ -591,7 +595,11 @@ def main():
                 "k_head_out (2-loop half of the pair probabilities, probe windows staged in LDS)",
                 b_head, ms_head, l_head, "k_outside_head")
         if args.workload != "batch10k":
-            res["ms_per_seq"] = elapsed * 1e3 / steps
+            # ms per sequence: median over the timed steps (>= 5 after a warm-up)
+            res["ms_per_seq"] = float(np.median(step_s)) * 1e3
+            res["ms_per_seq_all_steps"] = [round(x * 1e3, 2) for x in step_s]
+            res["ms_inside_per_step"] = ms_in / steps
+            res["ms_outside_per_step"] = ms_out / steps
         elif world == 1 and not args.no_n4096 and not args.rehearse_shard:
             # the other half of the metric: ms per sequence at n = 4096 (BASELINE.json
             # configs[2]: Turner), ONE timed call, device-resident (the median of >= 5 after a

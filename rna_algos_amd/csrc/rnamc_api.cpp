@@ -436,7 +436,11 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
           HIPCHK(hipEventRecord(c->ev_a[head_slot], st));
           HIPCHK(hipStreamWaitEvent(c->head_stream, c->ev_a[head_slot], 0));
           const uint32_t nd = std::min<uint32_t>(2u, gmax - (d + 2));
-          if (launch_head(b, contra, false, d + 2, nd, gmax, active(d + 2), static_cast<uint32_t>(c->head_wmax_in), c->head_stream) != 0) {
+          const int hrc = c->head_lds == 2
+                              ? launch_head_carry(b, contra, false, d + 2, nd, gmax, active(d + 2), c->head_stream)
+                              : launch_head(b, contra, false, d + 2, nd, gmax, active(d + 2),
+                                            static_cast<uint32_t>(c->head_wmax_in), c->head_stream);
+          if (hrc != 0) {
             set_last_error("k_head (inside): launch configuration rejected");
             return RNAMC_ERR_HIP;
           }
@@ -580,8 +584,10 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
             int hrc = 0;
             if (head && r_head) {
               timed(3, c->head_stream, [&]() {
-                hrc = launch_head(b, contra, true, d - 1, 1, gmax, na,
-                                  static_cast<uint32_t>(c->head_wmax_out), c->head_stream);
+                hrc = c->head_lds == 2
+                          ? launch_head_carry(b, contra, true, d - 1, 1, gmax, na, c->head_stream)
+                          : launch_head(b, contra, true, d - 1, 1, gmax, na,
+                                        static_cast<uint32_t>(c->head_wmax_out), c->head_stream);
               });
               c->stats.launches_outside++;
             }

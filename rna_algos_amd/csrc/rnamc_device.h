@@ -52,6 +52,10 @@ void launch_outside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_
 int launch_head(const DeviceBatch& b, bool contra, bool outside, uint32_t d0, uint32_t nd,
                 uint32_t max_n, uint32_t nseq, uint32_t wmax, hipStream_t st);
 size_t head_smem_bytes(bool outside, uint32_t wmax);
+// the same roles with carried operands: rows of probes are walked in pairs, the second row of a
+// pair reads from lane-private LDS slots what the first row fetched beside its own operands
+int launch_head_carry(const DeviceBatch& b, bool contra, bool outside, uint32_t d0, uint32_t nd,
+                      uint32_t max_n, uint32_t nseq, hipStream_t st);
 // Latency forms for groups too small to fill the chip (rnamc_latency.h): one wave per fold
 // chain.  A group that uses them uses them on EVERY diagonal (they keep W dense, and complete
 // sums_1ormore_basepairs of diagonal d-1 in the launch of diagonal d).

@@ -398,7 +398,7 @@ struct NoProbeTabs {
 template <bool WANT>
 using ProbeTabStore = typename std::conditional<WANT, ProbeTabs, NoProbeTabs>::type;
 
-template <bool CONTRA, int MODE, bool LDSW = false>
+template <bool CONTRA, int MODE, int SRC = 0>
 __device__ __forceinline__ void inside_pair_cell(const DeviceBatch& b, const Seq& q, uint32_t d,
                                                  uint32_t i, bool valid, const LseTab* tab,
                                                  const ProbeTabs& L, const float* win = nullptr,
@@ -420,7 +420,7 @@ __device__ __forceinline__ void inside_pair_cell(const DeviceBatch& b, const Seq
     // a+bb <= 30, k < j-1, l > k   <=>   a + bb <= d-3   (uniform over the diagonal)
     if (d >= 3) {
       const uint32_t lim = min(static_cast<uint32_t>(RNAMC_MAX_2LOOP_LEN), d - 3);
-      sum = probe_fold<CONTRA, false, LDSW>(b, q, d, i, act, lim, sum, 0.f, tab, L, win, wp, wi);
+      sum = probe_fold<CONTRA, false, SRC>(b, q, d, i, act, lim, sum, 0.f, tab, L, win, wp, wi);
     }
     if (!act) return;
     if (MODE == PAIR_HEAD) {
@@ -1138,7 +1138,7 @@ __device__ __forceinline__ void outside_mb_cell(const DeviceBatch& b, const Seq&
 // pair probability of one cell, first half: exterior term ⊕ enclosing 2-loops
 // (559-593 / 663-700).  Needs only results of spans >= span+2, so it runs one
 // launch ahead of the second half and parks the running sum in the log-prob slot.
-template <bool CONTRA, bool LDSW = false>
+template <bool CONTRA, int SRC = 0>
 __device__ __forceinline__ void outside_pair_head(const DeviceBatch& b, const Seq& q, uint32_t d,
                                                   uint32_t i, bool valid, const LseTab* tab,
                                                   const ProbeTabs& L, const float* win = nullptr,
@@ -1166,7 +1166,7 @@ __device__ __forceinline__ void outside_pair_head(const DeviceBatch& b, const Se
   // a + bb <= 30, k >= 0, l <= n-1; rows with d+2+a > n-1 have no diagonal left
   if (d + 2 < n) {
     const uint32_t lim = min(static_cast<uint32_t>(RNAMC_MAX_2LOOP_LEN), n - 3 - d);
-    p = probe_fold<CONTRA, true, LDSW>(b, q, d, i, paired, lim, p, qb_ij, tab, L, win, wp, wi);
+    p = probe_fold<CONTRA, true, SRC>(b, q, d, i, paired, lim, p, qb_ij, tab, L, win, wp, wi);
   }
   if (paired) q.m[M_P][od] = p;
 }
@@ -1472,9 +1472,9 @@ __global__ void __launch_bounds__(kHeadBlock)
       const bool mine = tid < take;
       const uint32_t wi = mine ? i - p0 : 0u;  // idle lanes of the wave stay inside the window
       if (!OUTSIDE) {
-        inside_pair_cell<CONTRA, PAIR_HEAD, true>(b, q, dp, mine ? i : 0u, mine, tabs, L, win, wp, wi);
+        inside_pair_cell<CONTRA, PAIR_HEAD, 1>(b, q, dp, mine ? i : 0u, mine, tabs, L, win, wp, wi);
       } else {
-        outside_pair_head<CONTRA, true>(b, q, dp, mine ? i : 0u, mine, tabs, L, win, wp, wi);
+        outside_pair_head<CONTRA, 1>(b, q, dp, mine ? i : 0u, mine, tabs, L, win, wp, wi);
       }
     }
     start += take;
@@ -1693,6 +1693,38 @@ __global__ void __launch_bounds__(64) k_pair_lat(DeviceBatch b, uint32_t d, uint
     outside_head_lat<CONTRA>(b, q, d, i, P8);
   } else {
     inside_pair_lat<CONTRA, PAIR_FULL>(b, q, d, i, P8);
+  }
+}
+
+// The 2-loop halves with carried operands (probe_fold SRC 2): one lane per listed cell,
+// kCarryBlock cells per workgroup, lane-private LDS slots carry[31][kCarryBlock] (floats
+// inside, {log prob, sums_close} pairs outside) after the tables.
+template <bool CONTRA, bool OUTSIDE, uint32_t BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+    k_head_carry(DeviceBatch b, uint32_t d0, uint32_t blocks_d, uint32_t nseq) {
+  extern __shared__ __align__(16) unsigned char head_smem[];
+  LseTab* tabs = reinterpret_cast<LseTab*>(head_smem);
+  ProbeTabs& L = *reinterpret_cast<ProbeTabs*>(head_smem + sizeof(LseTab));
+  float* carry = reinterpret_cast<float*>(head_smem + kHeadTabBytes);
+  const uint32_t bxr = blockIdx.x / nseq;
+  const uint32_t which = blockIdx.x - bxr * nseq;
+  const Seq q = load_seq(b, which);
+  const uint32_t n = q.n;
+  const uint32_t dp = d0 + bxr / blocks_d;
+  const uint32_t blk = bxr % blocks_d;
+  if (dp >= n) return;
+  const uint32_t cnt = q.ccnt[dp];
+  if (blk * BLOCK >= cnt) return;  // uniform over the block
+  load_lse_table(tabs);
+  load_probe_tabs<CONTRA, OUTSIDE>(L, b.params);
+  const uint32_t t = blk * BLOCK + threadIdx.x;
+  if (t - (threadIdx.x & 63u) >= cnt) return;  // wave past the list
+  uint32_t i;
+  const bool valid = listed_cell(q, dp, t, cnt, i);
+  if (!OUTSIDE) {
+    inside_pair_cell<CONTRA, PAIR_HEAD, 2>(b, q, dp, i, valid, tabs, L, carry, BLOCK, threadIdx.x);
+  } else {
+    outside_pair_head<CONTRA, 2>(b, q, dp, i, valid, tabs, L, carry, BLOCK, threadIdx.x);
   }
 }
 
@@ -1929,6 +1961,36 @@ int launch_head(const DeviceBatch& b, bool contra, bool outside, uint32_t d0, ui
     if (outside) RNAMC_LAUNCH_HEAD(false, true); else RNAMC_LAUNCH_HEAD(false, false);
   }
 #undef RNAMC_LAUNCH_HEAD
+  return 0;
+}
+
+// the same with carried operands (k_head_carry): every second row of probes reads LDS
+constexpr uint32_t kCarryBlockIn = 256, kCarryBlockOut = 512;
+int launch_head_carry(const DeviceBatch& b, bool contra, bool outside, uint32_t d0, uint32_t nd,
+                      uint32_t max_n, uint32_t nseq, hipStream_t st) {
+  if (d0 >= max_n || nseq == 0 || nd == 0) return 0;
+  const uint32_t block = outside ? kCarryBlockOut : kCarryBlockIn;
+  const uint32_t bd = (max_n - d0 + block - 1) / block;
+  const dim3 g(nd * bd * nseq, 1, 1);
+  const size_t smem = kHeadTabBytes + static_cast<size_t>(kHeadRows) * block * (outside ? 8u : 4u);
+  static bool attr_set[2][2] = {};
+#define RNAMC_LAUNCH_CARRY(C, O, BL)                                                                \
+  do {                                                                                              \
+    if (!attr_set[C][O]) {                                                                          \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_carry<C, O, BL>),    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,                \
+                                         static_cast<int>(smem));                                   \
+      if (e != hipSuccess) return static_cast<int>(e);                                              \
+      attr_set[C][O] = true;                                                                        \
+    }                                                                                               \
+    hipLaunchKernelGGL((k_head_carry<C, O, BL>), g, dim3(BL), smem, st, b, d0, bd, nseq);           \
+  } while (0)
+  if (contra) {
+    if (outside) RNAMC_LAUNCH_CARRY(true, true, kCarryBlockOut); else RNAMC_LAUNCH_CARRY(true, false, kCarryBlockIn);
+  } else {
+    if (outside) RNAMC_LAUNCH_CARRY(false, true, kCarryBlockOut); else RNAMC_LAUNCH_CARRY(false, false, kCarryBlockIn);
+  }
+#undef RNAMC_LAUNCH_CARRY
   return 0;
 }
 

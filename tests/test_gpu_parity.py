@@ -542,6 +542,11 @@ def test_lds_staged_probe_windows_bit_exact(params, contra, short):
             st = ctx.stats()
             assert st["launches_outside_head"] > 300 and st["ms_outside_head"] > 0
             assert st["launches_outside_main"] == st["launches_outside_tail"]
+        # the carried-operand form: rows of probes in pairs, the second row's operands parked in
+        # lane-private LDS slots by the first
+        ctx.set("head_lds", 2)
+        runs.append(ctx.bpp_batch(seqs, contra, short))
+        assert ctx.stats()["launches_outside_head"] > 300
     finally:
         ctx.close()
     ref, ref_logz = O.bpp_batch(params.ptr, seqs, contra, short, n_threads=16)
