@@ -1068,7 +1068,7 @@ int rnamc_bpp_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* bases, const u
                           c->own_stream));
   HIPCHK(hipStreamSynchronize(c->own_stream));
   for (int k = 0; k < 2; k++)
-    if (c->st_out_cap[k] > (2ull << 30)) {  // a big one-off batch should not keep its result staged
+    if (c->st_out_cap[k] > (24ull << 30)) {  // (two group buffers stay for the next call unless huge)
       (void)hipFree(c->st_out[k]);
       c->st_out[k] = nullptr;
       c->st_out_cap[k] = 0;

@@ -39,6 +39,14 @@ def main():
             "group_max_seqs": int(rng.choice([3, 17, 8192])),
             "order_outside": int(rng.integers(0, 5)),
             "order_inside": int(rng.integers(0, 3)),
+            # round 2: latency forms and the optional 2-loop kernels
+            "latency_mode": int(rng.choice([0, 1, 1, 2])),
+            "lat_pairs": int(rng.integers(0, 2)),
+            "lat_inside": int(rng.integers(0, 2)),
+            "lat_inside_waves": int(rng.choice([0, 300, 2048, 1 << 20])),
+            "head_lds": int(rng.choice([0, 0, 1, 2])),
+            "head_wmax_in": int(rng.choice([64, 200, 448])),
+            "head_wmax_out": int(rng.choice([64, 200, 448])),
         }
         for k, v in knobs.items():
             ctx.set(k, v)
@@ -52,6 +60,13 @@ def main():
         alphabet = int(rng.choice([2, 3, 4, 4, 4]))
         seqs = [rng.integers(0, alphabet, int(n)).astype(np.uint8) for n in lens]
         contra, short = [(False, False), (True, False), (True, True)][int(rng.integers(0, 3))]
+        if int(rng.integers(0, 4)) == 0:
+            # the tables follow the caller's set: a context built on other tables, re-pointed
+            ctx.close()
+            ctx = Context(FoldScoreSets.synthetic(99), device=0)
+            for k, v in knobs.items():
+                ctx.set(k, v)
+            ctx.sync_params(P)
         mats, logz = ctx.bpp_batch(seqs, contra, short)
         ref, rz = O.bpp_batch(P.ptr, seqs, contra, short, n_threads=16)
         ok = all(same(np.asarray(m.packed), x) for m, x in zip(mats, ref)) and \
