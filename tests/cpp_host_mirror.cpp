@@ -1,11 +1,13 @@
-// The reference's own integration test (tests/tests.rs:7-43) written against the C++
-// host mirror: 6 tRNAs, both models, every bpp value in [-0.001, 1.001).
+// The reference's own integration tests (tests/tests.rs:7-43 test_mccaskill_algo and 45-80
+// test_durbin_algo) written against the C++ host mirror: 6 tRNAs, both models, every bpp value
+// in [-0.001, 1.001); all 15 pairs, every match probability in the same range.
 // Exit 0 = pass, 77 = no GPU (the library refuses to run), anything else = failure.
 #include <cstdio>
 #include <fstream>
 #include <string>
 #include <vector>
 
+#include "rna_algos/durbin_algo.hpp"
 #include "rna_algos/mccaskill_algo.hpp"
 
 using namespace rna_algos;
@@ -49,6 +51,28 @@ int main(int argc, char** argv) {
       for (const auto& kv : r.first)
         if (fs.accessible_scores.find(kv.first) == fs.accessible_scores.end()) return 9;
       if (fs.hairpin_scores.size() < r.first.size() || fs.twoloop_scores.empty()) return 10;
+    }
+    {  // test_durbin_algo, tests/tests.rs:45-80
+      std::vector<Seq> padded;
+      for (const Seq& z : seqs) {
+        Seq y = z;
+        y.insert(y.begin(), PSEUDO_BASE);
+        y.push_back(PSEUDO_BASE);
+        padded.push_back(y);
+      }
+      AlignScores align_scores = AlignScores::new_(0.f);
+      align_scores.transfer();
+      std::vector<std::pair<size_t, size_t>> pairs;
+      for (size_t i = 0; i < padded.size(); i++)
+        for (size_t j = i + 1; j < padded.size(); j++) pairs.emplace_back(i, j);
+      auto mats = durbin_algo_batch(ctx, padded, pairs, align_scores);
+      if (mats.size() != 15) return 11;
+      for (const ProbMat& m : mats)
+        for (const Probs& row : m)
+          for (Prob x : row)
+            if (!(x >= PROB_BOUND_LOWER && x < PROB_BOUND_UPPER)) return 12;
+      ProbMat one = durbin_algo(ctx, SeqPair(&padded[0], &padded[1]), align_scores);
+      if (one != mats[0]) return 13;
     }
     try {  // a byte outside ACGU: the reference panics
       bytes2seq("ACGT");
