@@ -33,7 +33,9 @@ enum Mat : int {
   M_W = 8,    // (P + mbclose) - Qb of a pair        diag-major (outside pass)
   M_ZRM = 9,  // sums_rightmost_basepairs_multibranch diag-major (CONTRAfold, inside pass)
   M_P = 9,    // log basepair_probs                  diag-major (outside pass, same slot)
-  M_COUNT = 10
+  M_PQ = 10,  // {log basepair_prob, sums_close} of a FINISHED pair, interleaved (float2, two
+              // slots), diag-major: the enclosing-pair probes read both with one 8-byte gather
+  M_COUNT = 12
 };
 
 struct SeqDesc {

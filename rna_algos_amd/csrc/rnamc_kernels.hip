@@ -1256,6 +1256,7 @@ __device__ __forceinline__ void outside_pair_tail(const DeviceBatch& b, const Se
   }
   if (paired && p > kNegInf) {
     q.m[M_P][od] = p;
+    reinterpret_cast<float2*>(q.m[M_PQ])[od] = make_float2(p, qb_ij);
     q.m[M_W][tri_off(n, d) + tl] = p + q.m[M_MBC][od] - qb_ij;  // list index, see outside_mb_cell
   }
 }

@@ -297,6 +297,7 @@ __device__ __forceinline__ void outside_tail_lat(const DeviceBatch& b, const Seq
   }
   if (lane == 0u && p > kNegInf) {
     q.m[M_P][od] = p;
+    reinterpret_cast<float2*>(q.m[M_PQ])[od] = make_float2(p, qb_ij);
     q.m[M_W][od] = p + q.m[M_MBC][od] - qb_ij;  // dense: read by outside_mb_lat
   }
 }

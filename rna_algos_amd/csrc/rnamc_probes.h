@@ -271,6 +271,7 @@ __device__ __forceinline__ float probe_fold(const DeviceBatch& b, const Seq& q, 
   const uint32_t j = i + d;
   const float* __restrict__ qb = q.m[M_QB];
   const float* __restrict__ lp = q.m[M_P];
+  const float2* __restrict__ pq = reinterpret_cast<const float2*>(q.m[M_PQ]);
   const uint32_t i4 = i * 4u;
   // windows: wa walks with a (the k side), wb walks with b (the l side)
   //  inside : wa = bases i .. i+31 (k-1 at position a, k at a+1)
@@ -402,8 +403,16 @@ __device__ __forceinline__ float probe_fold(const DeviceBatch& b, const Seq& q, 
 #pragma unroll
     for (int u = 0; u < kPU; u++) {
       const uint32_t bb = min(rb + static_cast<uint32_t>(u), blast);
-      B.xs[u] = ldu(ubase(qb, ra, bb), i4);
-      B.ps[u] = OUTSIDE ? ldu(ubase(lp, ra, bb), i4) : 0.f;
+      if (OUTSIDE) {
+        // {log prob, sums_close} of the enclosing pair with ONE 8-byte gather (M_PQ)
+        const float2* base2 = pq + tri_off(n, d + 2 + ra + bb) - 1 - ra;
+        const float2 v = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(base2) + 2u * i4);
+        B.ps[u] = v.x;
+        B.xs[u] = v.y;
+      } else {
+        B.xs[u] = ldu(ubase(qb, ra, bb), i4);
+        B.ps[u] = 0.f;
+      }
     }
   };
   // outside: lane-level validity of (k,l): k = i-1-a >= 0 and l = j+1+bb <= n-1
