@@ -1014,7 +1014,13 @@ int rnamc_bpp_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* bases, const u
       cv.notify_all();
     }
   };
-  std::thread drainer(drain);
+  std::thread drainer;
+  try {
+    drainer = std::thread(drain);
+  } catch (...) {  // no thread: nothing has been enqueued yet
+    set_last_error("rnamc_bpp_batch: could not start the result-drain thread");
+    return RNAMC_ERR_OOM;
+  }
   GroupHooks hooks;
   hooks.before = [&](size_t g, float** out_base) -> int {
     const int k = static_cast<int>(g & 1);

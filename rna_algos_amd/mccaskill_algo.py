@@ -124,7 +124,10 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            _lib.lib().rnamc_ctx_destroy(self._h)
+            try:
+                _lib.lib().rnamc_ctx_destroy(self._h)
+            except Exception:  # interpreter shutdown: the binding module is already torn down
+                pass
             self._h = C.c_void_p()
 
     __del__ = close
