@@ -500,9 +500,32 @@ def main():
     pres = probe[probe >= -0.5]
     assert pres.numel() > 0 and float(pres.min()) >= -0.001 and float(pres.max()) < 1.05
     assert bool(torch.isfinite(d_logz).all())
+    # also the golden member of the 2048-nt class (tests/golden/checksums_batch2k.json)
+    if args.workload == "batch10k" and args.param_seed == 1 and args.batch_count == 10000:
+        try:
+            gold2 = json.load(open(os.path.join(ROOT, "tests", "golden", "checksums_batch2k.json")))["cases"]
+        except OSError:
+            gold2 = {}
+        where = {int(g): x for x, g in enumerate(mine)}
+        for key, info in gold2.items():
+            idx = int(key.split("_")[0][len("batch"):])
+            if key.endswith("contra") != contra or idx not in where:
+                continue
+            x = where[idx]
+            got = d_out[int(out_offsets[x]):int(out_offsets[x + 1])].cpu().numpy()
+            checked += 1
+            if golden_digest(got) != info["sha256"] or len(my_seqs[x]) != info["n"]:
+                failed += 1
+    if world > 1:
+        # every rank checks the golden members of ITS shard; rank 0 reports the sum
+        cf = torch.tensor([checked, failed], dtype=torch.int64,
+                          device=dev if args.backend == "nccl" else torch.device("cpu"))
+        dist.all_reduce(cf, op=dist.ReduceOp.SUM)
+        checked, failed = (int(x) for x in cf.tolist())
     if failed:
-        print(f"bench.py: {failed} of {checked} golden batch members differ from the oracle's "
-              f"checksum", file=sys.stderr)
+        if rank == 0:
+            print(f"bench.py: {failed} of {checked} golden batch members differ from the oracle's "
+                  f"checksum", file=sys.stderr)
         sys.exit(3)
 
     if rank == 0:
@@ -555,7 +578,7 @@ def main():
                 "paired_fraction_f": f,
             },
             "parity_check": (f"{checked}/{checked} golden members (sha256 of the whole matrix "
-                             f"against the oracle's, tests/golden/checksums_batch.json)")
+                             f"against the oracle's, tests/golden/checksums_batch*.json)")
             if checked else "none of the golden members is in this run",
             "value_with_transfers": with_transfers["value"] if with_transfers else None,
             "with_transfers": with_transfers,
