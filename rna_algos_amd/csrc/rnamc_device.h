@@ -60,7 +60,7 @@ int launch_head_carry(const DeviceBatch& b, bool contra, bool outside, uint32_t 
 // chain.  A group that uses them uses them on EVERY diagonal (they keep W dense, and complete
 // sums_1ormore_basepairs of diagonal d-1 in the launch of diagonal d).
 void launch_inside_lat(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
-                       bool do_chains, bool do_combine, hipStream_t st);
+                       int form, bool do_combine, hipStream_t st);
 void launch_outside_lat(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
                         bool do_mb, bool do_tail, hipStream_t st);
 // closing-pair block (inside) / 2-loop half of the pair probabilities (outside) of diagonal d

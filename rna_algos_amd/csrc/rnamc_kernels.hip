@@ -1489,20 +1489,30 @@ __global__ void __launch_bounds__(kHeadBlock)
 // diagonal d-1 for the combine that completes sums_1ormore_basepairs (do_combine).
 template <bool CONTRA>
 __global__ void __launch_bounds__(64) k_inside_lat(DeviceBatch b, uint32_t d, uint32_t cells_max,
-                                                   uint32_t nseq, int do_chains, int do_combine) {
+                                                   uint32_t nseq, int form, int do_combine) {
   __shared__ LseTab tabs;
   const uint32_t bx = blockIdx.x / nseq;
   const uint32_t which = blockIdx.x - bx * nseq;
   const Seq q = load_seq(b, which);
   const uint32_t n = q.n;
-  if (bx < 3u * cells_max) {
-    const uint32_t i = bx / 3u, role = bx - 3u * i;
-    if (!do_chains || d >= n || i >= n - d) return;
+  // form 1: one wave per (cell, role); form 2: eight cells of one role per wave; 0: no chains
+  const uint32_t per = form == 2 ? 8u : 1u;
+  const uint32_t wpr = (cells_max + per - 1u) / per;  // waves per role
+  const uint32_t nchain = form ? 3u * wpr : 0u;
+  if (bx < nchain) {
+    const uint32_t w = bx / 3u, role = bx - 3u * w;
+    if (d >= n || w * per >= n - d) return;
     const Piece8 P8 = load_piece8();
-    inside_chain_lat<CONTRA>(b, q, d, i, role, P8);
+    if (form == 2) {
+      if (role == 0) inside_chain_e<CONTRA, 0>(b, q, d, w * 8u, P8);
+      else if (role == 1) inside_chain_e<CONTRA, 1>(b, q, d, w * 8u, P8);
+      else inside_chain_e<CONTRA, 2>(b, q, d, w * 8u, P8);
+    } else {
+      inside_chain_lat<CONTRA>(b, q, d, w, role, P8);
+    }
   } else {
     if (!do_combine || d == 0 || d - 1 >= n) return;
-    const uint32_t i0 = (bx - 3u * cells_max) * 64u;
+    const uint32_t i0 = (bx - nchain) * 64u;
     if (i0 >= n - (d - 1)) return;
     load_lse_table(&tabs);
     const uint32_t i = i0 + (threadIdx.x & 63u);
@@ -1871,20 +1881,23 @@ void launch_outside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_
 #undef RNAMC_LAUNCH_OUT
 }
 
-// latency forms (rnamc_latency.h): the fold chains of diagonal d (do_chains) and the combine
-// that completes sums_1ormore_basepairs of diagonal d-1 (do_combine)
+// latency forms (rnamc_latency.h): the fold chains of diagonal d (form 1: one wave per chain,
+// 2: eight chains per wave, 0: none) and the combine that completes sums_1ormore_basepairs of
+// diagonal d-1 (do_combine)
 void launch_inside_lat(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
-                       bool do_chains, bool do_combine, hipStream_t st) {
+                       int form, bool do_combine, hipStream_t st) {
   if (nseq == 0) return;
-  const uint32_t cells = (do_chains && d < max_n) ? max_n - d : 0;
+  const uint32_t cells = (form && d < max_n) ? max_n - d : 0;
+  const uint32_t per = form == 2 ? 8u : 1u;
+  const uint32_t waves = 3u * ((cells + per - 1u) / per);
   const uint32_t cb = (do_combine && d >= 1 && d - 1 < max_n) ? (max_n - d + 1 + 63) / 64 : 0;
-  if (3 * cells + cb == 0) return;
-  const dim3 g((3 * cells + cb) * nseq, 1, 1);
-  const int a0 = do_chains ? 1 : 0, a1 = do_combine ? 1 : 0;
+  if (waves + cb == 0) return;
+  const dim3 g((waves + cb) * nseq, 1, 1);
+  const int a1 = do_combine ? 1 : 0;
   if (contra) {
-    hipLaunchKernelGGL(k_inside_lat<true>, g, dim3(64), 0, st, b, d, cells, nseq, a0, a1);
+    hipLaunchKernelGGL(k_inside_lat<true>, g, dim3(64), 0, st, b, d, cells, nseq, cells ? form : 0, a1);
   } else {
-    hipLaunchKernelGGL(k_inside_lat<false>, g, dim3(64), 0, st, b, d, cells, nseq, a0, a1);
+    hipLaunchKernelGGL(k_inside_lat<false>, g, dim3(64), 0, st, b, d, cells, nseq, cells ? form : 0, a1);
   }
 }
 

@@ -181,6 +181,122 @@ __device__ __forceinline__ void inside_chain_lat(const DeviceBatch& b, const Seq
   }
 }
 
+// ----------------------------------------------------------------------------
+// inside, eight chains per wave: lanes 8g..8g+7 hold the chain of cell cell0 + g (one role per
+// wave, as above), lane p of a group evaluates cubic piece p and an OR over the group (3 DPP
+// steps) picks the piece whose interval holds z: the LDS-table round trips (60 % of a
+// dependent step of the three-lanes-per-cell form) leave the chain.  No scalar fast path here:
+// eight independent chains are hardly ever all in the identity piece at once.
+__device__ __forceinline__ float lse8(float sum, float x, const Piece8& P) {
+  const float hi = vmax(sum, x);
+  const float lo = vmin(sum, x);
+  const float z = hi - lo;  // >= 0; +inf or NaN when lo is -inf
+  float r = ((P.c0 * z + P.c1) * z + P.c2) * z + P.c3;
+  r = lo + r;
+  const bool sel = (z >= P.tlo) && (z < P.thi);
+  uint32_t v = sel ? __float_as_uint(r) : 0u;
+  v = dpp_or<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_or<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_or<0x141>(v);  // row_half_mirror: the other quad of the 8
+  // z >= 11.862479: identity piece lo + z; lo = -inf (z +inf or NaN): the sum is hi
+  const float alt = (lo == kNegInf) ? hi : lo + z;
+  return (z < 11.862479f) ? __uint_as_float(v) : alt;
+}
+
+constexpr int kUE = 16;  // fold steps per operand buffer (two buffers)
+
+// (ROLE is a template parameter: chosen per step at run time, the wave-uniform role conditions
+// became a handful of scalar branches in every fold step)
+template <bool CONTRA, uint32_t ROLE>
+__device__ __forceinline__ void inside_chain_e(const DeviceBatch& b, const Seq& q, uint32_t d,
+                                               uint32_t cell0, const Piece8& P8) {
+  constexpr uint32_t role = ROLE;
+  const uint32_t n = q.n;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t cells = n - d;
+  const uint32_t ic = cell0 + (lane >> 3);
+  const bool valid = ic < cells;
+  const uint32_t i = valid ? ic : cells - 1u;  // groups past the diagonal shadow its last cell
+  const bool leader = valid && (lane & 7u) == 0u;
+  const uint32_t od = tri_off(n, d) + i;
+  const float* __restrict__ zre = q.m[M_ZRE];
+  const float* __restrict__ zrm = q.m[CONTRA ? M_ZRM : M_ZRE];
+  const float* __restrict__ qa = q.m[M_QA];
+  float zr = kNegInf, c = 0.f, mun = 0.f;
+  if (!CONTRA) {
+    const float prev = (d >= 1) ? zre[tri_off(n, d - 1) + i] : kNegInf;
+    zr = lse8(prev, qa[od], P8);
+    if (leader && role == 0) q.m[M_ZRE][od] = zr;
+    c = b.params->turner.coeff_num_branches;
+  } else {
+    const rnamc_fold_score_sets& f = b.params->contra;
+    mun = f.multibranch_score_unpair;
+    if (role < 2) {
+      const float Pc = (role == 0) ? f.external_score_basepair : f.multibranch_score_basepair;
+      const float Qc = (role == 0) ? f.external_score_unpair : mun;
+      struct ABuf {
+        float xs[kUE];
+      };
+      uint32_t t = pingpong<ABuf, kUE, true>(
+          1u, d / kUE,
+          [&](ABuf& B, uint32_t t0) {
+#pragma unroll
+            for (int u = 0; u < kUE; u++) B.xs[u] = qa[tri_off(n, t0 + u) + i];
+          },
+          [&](const ABuf& B, uint32_t t0) {
+#pragma unroll
+            for (int u = 0; u < kUE; u++)
+              zr = lse8(zr, B.xs[u] + Pc + Qc * static_cast<float>(d - t0 - u), P8);
+          });
+      for (; t <= d; t++)
+        zr = lse8(zr, qa[tri_off(n, t) + i] + Pc + Qc * static_cast<float>(d - t), P8);
+      if (leader) q.m[role == 0 ? M_ZRE : M_ZRM][od] = zr;
+    }
+  }
+  float acc;
+  if (role == 0) {
+    acc = CONTRA ? lse8(b.params->contra.external_score_unpair * static_cast<float>(d + 1), zr + 0.f, P8)
+                 : lse8(0.f, zr + 0.f, P8);  // k = i: Z[i][i-1] is the lower-triangle 0
+  } else if (role == 1) {
+    acc = CONTRA ? zr : zr + c;
+  } else {
+    acc = kNegInf;
+  }
+  const float* __restrict__ pa = (CONTRA && role != 0) ? zrm : zre;
+  const float* __restrict__ pb = q.m[role == 0 ? M_Z : M_Q1D];
+  auto step = [&](float ra, float rb, uint32_t t) {
+    float term;
+    if (!CONTRA) {
+      term = (role == 0) ? ra + rb : (role == 1 ? ra + c : rb + (ra + c));
+    } else {
+      term = (role == 1) ? ra + mun * static_cast<float>(t) : rb + ra;
+    }
+    acc = lse8(acc, term, P8);
+  };
+  struct SBuf {
+    float ra[kUE], rb[kUE];
+  };
+  uint32_t t = pingpong<SBuf, kUE, true>(
+      1u, d >= 1 ? (d - 1) / kUE : 0u,
+      [&](SBuf& B, uint32_t t0) {
+#pragma unroll
+        for (int u = 0; u < kUE; u++) {
+          B.ra[u] = pa[tri_off(n, d - t0 - u) + t0 + u + i];
+          B.rb[u] = pb[tri_off(n, t0 + u - 1) + i];
+        }
+      },
+      [&](const SBuf& B, uint32_t t0) {
+#pragma unroll
+        for (int u = 0; u < kUE; u++) step(B.ra[u], B.rb[u], t0 + u);
+      });
+  for (; t < d; t++) step(pa[tri_off(n, d - t) + t + i], pb[tri_off(n, t - 1) + i], t);
+  if (leader) {
+    if (role == 0) q.m[M_Z][od] = acc;
+    if (role == 1) q.m[M_Q1D][od] = acc;  // parked: inside_combine_lat turns it into sums_1ormore
+    if (role == 2) q.m[M_QM][od] = acc;
+  }
+}
+
 // sums_1ormore_basepairs(i,j) = parked first sum ⊕ sums_multibranch (374 / 512), both layouts.
 // One lane per cell; runs in the launch of the NEXT diagonal (whose folds read nothing newer
 // than diagonal d-1 of this matrix).

@@ -92,6 +92,12 @@ def main():
         elif w == "n4096":
             run(ctx, [WL0.synthetic_seq(4096, 4096)], False, label="n4096")
             run(ctx, [WL0.synthetic_seq(4096, 4096)], True, reps=1, label="n4096")
+        elif w.startswith("multi"):
+            # multi<cnt>x<n>: cnt sequences of n nt in one group (latency-form crossover)
+            cnt, n = (int(x) for x in w[5:].split("x"))
+            seqs = [WL0.synthetic_seq(n, 77 * n + s) for s in range(cnt)]
+            run(ctx, seqs, False, label=w)
+            run(ctx, seqs, True, label=w)
         elif w.startswith("top"):
             # the `cnt` longest sequences of the 10k batch: what one lock-step group really holds
             cnt = int(w[3:])

@@ -665,17 +665,20 @@ def test_latency_forms_bit_exact(params, contra, short):
         ctx.set("lat_inside_waves", 300)  # (mixed: three-lanes form first, wave form at the end)
         ctx.set("lat_pairs", 0)           # (2-loop blocks in their lane-per-cell form)
         lat3, logz4 = ctx.bpp_batch(seqs, contra, short)
+        ctx.set("lat_inside", 2)          # eight chains per wave, 8-lane speculative logsumexp
+        ctx.set("lat_pairs", 1)
+        lat4, logz5 = ctx.bpp_batch(seqs, contra, short)
         ctx.set("latency_mode", 1)    # default: a lone sequence takes the latency forms
         one, logz3 = ctx.bpp_batch([seqs[-4]], contra, short)
     finally:
         ctx.close()
     ref, ref_logz = O.bpp_batch(params.ptr, seqs, contra, short, n_threads=16)
-    for s, a, m, m2, m3, r in zip(seqs, base, lat, lat2, lat3, ref):
-        for got in (m, m2, m3):
+    for s, a, m, m2, m3, m4, r in zip(seqs, base, lat, lat2, lat3, lat4, ref):
+        for got in (m, m2, m3, m4):
             assert np.array_equal(np.asarray(a.packed).view(np.uint32),
                                   np.asarray(got.packed).view(np.uint32)), f"n={len(s)}"
         assert_same(m.packed, r, f"n={len(s)}")
-    for lz in (logz0, logz1, logz2, logz4):
+    for lz in (logz0, logz1, logz2, logz4, logz5):
         assert np.array_equal(np.asarray(lz).view(np.uint32), np.asarray(ref_logz).view(np.uint32))
     assert_same(one[0].packed, ref[-4], "lone sequence")
     assert np.float32(logz3[0]).view(np.uint32) == np.float32(ref_logz[-4]).view(np.uint32)
