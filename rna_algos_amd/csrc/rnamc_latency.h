@@ -86,6 +86,25 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) {
   return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v)));
 }
 
+// Terms classified AHEAD of the chain.  The terms of the next block of steps are computed
+// lane-parallel (lane l: step l); a term t with  -4096 < t < far_limit(sum at block start)
+// is certain to meet the identity piece when the chain reaches it, whatever the steps in
+// between did: a fold step never lowers the running sum by more than its two roundings
+// (every cubic piece returns more than z, and |sum|, |t| < 2^12 + 256 ln 2 keep z < 2^14, so
+// one step loses < 2^-10 + 2^-12 and 256 steps < 0.32 of the 1.0 kept in hand).  For such a
+// step logsumexp IS lse_far: hi = sum, lo = t, z = hi - lo >= 11.862479, result lo + z
+// (src/utils.rs:589-591) — two dependent instructions, no compare and no branch on the chain.
+// A term of -inf leaves the sum as it is (lse_u returns hi) and is skipped.
+__device__ __forceinline__ float far_limit(float sum) {
+  return (__builtin_fabsf(sum) < 4096.f) ? sum - 12.862479f : kNegInf;
+}
+__device__ __forceinline__ bool sure_far(float t, float lim) { return t < lim && t > -4096.f; }
+__device__ __forceinline__ float lse_far(float sum, float t) {
+  const float z = sum - t;
+  return t + z;
+}
+__device__ __forceinline__ bool bit(unsigned long long m, uint32_t l) { return (m >> l) & 1ull; }
+
 
 // ----------------------------------------------------------------------------
 // inside: one wave per (cell, role) of diagonal d
@@ -347,15 +366,27 @@ __device__ __forceinline__ void outside_mb_lat(const DeviceBatch& b, const Seq& 
       },
       [&](const MBuf& B, uint32_t t0) {
         const float bx = pin(B.x), br = pin(B.r);
-        unsigned long long m = __ballot(B.has != 0u);
+        // both chains' terms of step t0 + lane, classified against the sums at block start
+        const float a1 = bx + br;
+        const float a2 = CONTRA ? bx + mun * static_cast<float>(t0 + lane - 1u) : bx;
+        const bool has1 = B.has != 0u && t0 + lane >= 2u;  // (t = 1: only pm2 moves)
+        const float l1 = far_limit(pm), l2 = far_limit(pm2);
+        const unsigned long long f1 = __ballot(has1 && sure_far(a1, l1));
+        const unsigned long long f2 = __ballot(B.has != 0u && sure_far(a2, l2));
+        const unsigned long long g1 = __ballot(has1 && a1 > kNegInf) & ~f1;
+        const unsigned long long g2 = __ballot(B.has != 0u && a2 > kNegInf) & ~f2;
+        const unsigned long long ff = f1 & f2;
+        unsigned long long m = f1 | f2 | g1 | g2;
         while (m) {
           const uint32_t l = static_cast<uint32_t>(__builtin_ctzll(m));
           m &= m - 1ull;
-          const uint32_t t = t0 + l;
-          const float x = lane_val(bx, l);
-          // t = 1: sums_1ormore_basepairs[j+1][j] is the empty interval: only pm2 moves
-          if (t >= 2u) pm = lse_u(pm, x + lane_val(br, l), P8);
-          pm2 = lse_u(pm2, CONTRA ? x + mun * static_cast<float>(t - 1u) : x, P8);
+          if (bit(ff, l)) {  // two independent two-instruction steps
+            pm = lse_far(pm, lane_val(a1, l));
+            pm2 = lse_far(pm2, lane_val(a2, l));
+          } else {
+            if (bit(f1 | g1, l)) pm = lse_u(pm, lane_val(a1, l), P8);
+            if (bit(f2 | g2, l)) pm2 = lse_u(pm2, lane_val(a2, l), P8);
+          }
         }
       });
   if (lane == 0u) reinterpret_cast<float2*>(q.m[M_PM])[col_off(j) + i] = make_float2(pm, pm2);
@@ -399,11 +430,32 @@ __device__ __forceinline__ void outside_tail_lat(const DeviceBatch& b, const Seq
       [&](const TBuf& B, uint32_t k0) {
         const uint32_t cnt = min(64u, full - k0);
         const float bx = pin(B.x), by = pin(B.yy.x), by2 = pin(B.yy.y);
-        for (uint32_t l = 0; l < cnt; l++) {
-          const float x = lane_val(bx, l), y = lane_val(by, l), y2 = lane_val(by2, l);
-          p = lse_u(p, sa + y2 + x, P8);
-          p = lse_u(p, CONTRA ? sa + y + mun * static_cast<float>(i - (k0 + l) - 1) : sa + y, P8);
-          p = lse_u(p, sa + x + y, P8);
+        // the three terms of k = k0 + lane, classified against p at block start
+        const float a0 = sa + by2 + bx;
+        const float a1 = CONTRA ? sa + by + mun * static_cast<float>(i - (k0 + lane) - 1) : sa + by;
+        const float a2 = sa + bx + by;
+        const float lim = far_limit(p);
+        const bool in = lane < cnt;
+        const unsigned long long f0 = __ballot(in && sure_far(a0, lim));
+        const unsigned long long f1 = __ballot(in && sure_far(a1, lim));
+        const unsigned long long f2 = __ballot(in && sure_far(a2, lim));
+        const unsigned long long n0 = __ballot(in && a0 > kNegInf);  // (far ones included)
+        const unsigned long long n1 = __ballot(in && a1 > kNegInf);
+        const unsigned long long n2 = __ballot(in && a2 > kNegInf);
+        const unsigned long long ff = f0 & f1 & f2;
+        unsigned long long m = n0 | n1 | n2;
+        while (m) {
+          const uint32_t l = static_cast<uint32_t>(__builtin_ctzll(m));
+          m &= m - 1ull;
+          if (bit(ff, l)) {
+            p = lse_far(p, lane_val(a0, l));
+            p = lse_far(p, lane_val(a1, l));
+            p = lse_far(p, lane_val(a2, l));
+          } else {
+            if (bit(n0, l)) p = lse_u(p, lane_val(a0, l), P8);
+            if (bit(n1, l)) p = lse_u(p, lane_val(a1, l), P8);
+            if (bit(n2, l)) p = lse_u(p, lane_val(a2, l), P8);
+          }
         }
       });
   if (i >= 1) {
