@@ -85,15 +85,16 @@ struct rnamc_ctx {
   // group's longest diagonal holds at most lat_max_cells cells over all its sequences, 2 always
   int64_t latency_mode = 1;
   int64_t lat_max_cells = 16384;
-  // inside folds of such a group: 0 the three-lanes-per-cell form throughout; 1 one wave per
-  // chain on the diagonals whose launches hold at most lat_inside_waves chains (3 per cell;
-  // measured equal for Turner, 5 % faster for CONTRAfold); 2 (default) eight chains per wave
-  // with the 8-lane speculative logsumexp on the diagonals whose launches need at most
-  // lat_e_waves waves (20-30 % faster for one sequence, 5-8 % for 8 x 2048; beyond ~2 waves
-  // per SIMD the form is issue-bound and loses: profiles/r02_latency_forms.txt)
+  // inside folds of such a group (lat_inside is a bit set, 0 = the three-lanes-per-cell form
+  // throughout): bit 0 one wave per chain (terms classified ahead of the chain, as in the
+  // outside forms) on the diagonals whose launches hold at most lat_inside_waves chains (3 per
+  // cell); bit 1 eight chains per wave with the 8-lane speculative logsumexp on the diagonals
+  // whose launches need at most lat_e_waves waves (beyond ~2 waves per SIMD that form is
+  // issue-bound and loses: profiles/r02_latency_forms.txt)
   int64_t lat_inside = 2;
   int64_t lat_inside_waves = 2048;
   int64_t lat_e_waves = 2048;
+  int64_t lat_split = 0;
   int64_t lat_pairs = 1;   // its 2-loop blocks run one wave per listed cell (both sweeps)
   int64_t head_wmax_in = 448, head_wmax_out = 448;
   // role mask of timing experiments (bit0 folds, 1 pair block, 2 mb, 3 pair probs); settable
@@ -397,10 +398,10 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
           // wave-per-chain form completes sums_1ormore_basepairs of diagonal d-1 in the launch
           // of diagonal d (sequences that end at d-1 included).
           const uint64_t chains = 3ull * (gmax - d) * active(d);
-          // lat_inside 1: one wave per chain on the diagonals with few chains; 2: eight chains
-          // per wave (8-lane speculative logsumexp) on every diagonal
-          const int form = (c->lat_inside == 2 && (chains + 7) / 8 <= static_cast<uint64_t>(c->lat_e_waves)) ? 2
-                           : (c->lat_inside == 1 && chains <= static_cast<uint64_t>(c->lat_inside_waves)) ? 1 : 0;
+          // lat_inside bit 0: one wave per chain on the diagonals with few chains; bit 1: eight
+          // chains per wave on the diagonals with few enough waves
+          const int form = ((c->lat_inside & 1) && chains <= static_cast<uint64_t>(c->lat_inside_waves)) ? 1
+                           : ((c->lat_inside & 2) && (chains + 7) / 8 <= static_cast<uint64_t>(c->lat_e_waves)) ? 2 : 0;
           const bool wave_form = form != 0;
           if (wave_form || combine_due) {
             launch_inside_lat(b, contra, d, gmax, active(d >= 1 ? d - 1 : 0), form, combine_due, st);
@@ -523,6 +524,10 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
           }
           HIPCHK(hipStreamWaitEvent(c->aux_stream, c->ev_a[pv], 0));
           if (d < gmax) {
+            if (c->lat_split != 0) {
+              timed(1, st, [&]() { launch_outside_lat(b, contra, d, gmax, active(d), r_mb, false, st); });
+              timed(0, st, [&]() { launch_outside_lat(b, contra, d, gmax, active(d), false, r_tail, st); });
+            } else
             timed(0, st, [&]() { launch_outside_lat(b, contra, d, gmax, active(d), r_mb, r_tail, st); });
             c->stats.launches_outside++;
           }
@@ -865,10 +870,12 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     c->latency_mode = value;
   } else if (k == "lat_max_cells" && value >= 0) {
     c->lat_max_cells = value;
-  } else if (k == "lat_inside") {
+  } else if (k == "lat_inside" && value >= 0 && value <= 3) {
     c->lat_inside = value;
   } else if (k == "lat_inside_waves" && value >= 0) {
     c->lat_inside_waves = value;
+  } else if (k == "lat_split") {
+    c->lat_split = value;
   } else if (k == "lat_e_waves" && value >= 0) {
     c->lat_e_waves = value;
   } else if (k == "lat_pairs") {

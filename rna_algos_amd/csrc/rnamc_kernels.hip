@@ -2017,3 +2017,4 @@ void launch_finalize(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, uint32
 }
 
 }  // namespace rnamc
+

@@ -86,24 +86,80 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) {
   return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v)));
 }
 
-// Terms classified AHEAD of the chain.  The terms of the next block of steps are computed
-// lane-parallel (lane l: step l); a term t with  -4096 < t < far_limit(sum at block start)
-// is certain to meet the identity piece when the chain reaches it, whatever the steps in
-// between did: a fold step never lowers the running sum by more than its two roundings
-// (every cubic piece returns more than z, and |sum|, |t| < 2^12 + 256 ln 2 keep z < 2^14, so
-// one step loses < 2^-10 + 2^-12 and 256 steps < 0.32 of the 1.0 kept in hand).  For such a
-// step logsumexp IS lse_far: hi = sum, lo = t, z = hi - lo >= 11.862479, result lo + z
-// (src/utils.rs:589-591) — two dependent instructions, no compare and no branch on the chain.
-// A term of -inf leaves the sum as it is (lse_u returns hi) and is skipped.
-__device__ __forceinline__ float far_limit(float sum) {
-  return (__builtin_fabsf(sum) < 4096.f) ? sum - 12.862479f : kNegInf;
+// Terms classified AHEAD of the chain.  The terms of the next block of steps (at most 256)
+// are computed lane-parallel; a finite term t < far_limit(sum at block start, ...) is certain
+// to meet the identity piece when the chain reaches it, whatever the steps in between did:
+// a fold step never lowers the running sum by more than its two roundings (every cubic piece
+// returns more than z).  With M >= every |term| of the block and >= |sum| + 256 (the sum
+// gains at most ln 2 per step), z < 2 M, one step loses < 1.5 M 2^-23 and 256 steps
+// < M 2^-14.4: the margin kept in hand is 1 for M < 2^12, 4 below 2^16, 64 below 2^20, and
+// beyond that nothing is classified.  For such a step logsumexp IS lse_far: hi = sum,
+// lo = t, z = hi - lo >= 11.862479, result lo + z (src/utils.rs:589-591) — two dependent
+// instructions, no compare and no branch on the chain.  A term of -inf leaves the sum as it
+// is (lse_u returns hi) and is no step at all.
+// `mag`: this lane's largest finite |term| (0 if it has none).
+__device__ __forceinline__ float far_limit(float sum, float mag) {
+  const float m = vmax(mag, __builtin_fabsf(sum) + 256.f);  // (sum = -inf: nothing classified)
+  const bool b12 = __builtin_amdgcn_ballot_w64(m >= 4096.f) != 0ull;
+  const bool b16 = __builtin_amdgcn_ballot_w64(m >= 65536.f) != 0ull;
+  const bool b20 = __builtin_amdgcn_ballot_w64(m >= 1048576.f) != 0ull;
+  const float margin = !b12 ? 1.f : !b16 ? 4.f : !b20 ? 64.f : __builtin_inff();
+  return sum - (11.862479f + margin);
 }
-__device__ __forceinline__ bool sure_far(float t, float lim) { return t < lim && t > -4096.f; }
+__device__ __forceinline__ bool sure_far(float t, float lim) { return t < lim && t > kNegInf; }
 __device__ __forceinline__ float lse_far(float sum, float t) {
   const float z = sum - t;
   return t + z;
 }
-__device__ __forceinline__ bool bit(unsigned long long m, uint32_t l) { return (m >> l) & 1ull; }
+
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {  // set bits of m below this lane
+  return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                   __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+}
+
+// One block of a chain whose steps come NT per lane (lane l: steps NT*l .. NT*l + NT-1, a
+// term of -inf = no step).  The finite terms are compacted in step order through LDS
+// (`buf`: 64 * NT floats of this wave's own), classified against the sum at block start,
+// and the chain then alternates between runs of sure-far steps — a loop of one lane read
+// and the two instructions of lse_far per step — and single general steps.
+template <int NT>
+__device__ __forceinline__ float fold_block(float sum, const float (&a)[NT], float* buf,
+                                            const Piece8& P8) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t pos = 0, total = 0;
+  float mag = 0.f;
+#pragma unroll
+  for (int c = 0; c < NT; c++) {
+    const unsigned long long present = __builtin_amdgcn_ballot_w64(a[c] > kNegInf);
+    pos += lanes_below(present);
+    total += static_cast<uint32_t>(__popcll(present));
+    if (a[c] > kNegInf) mag = vmax(mag, __builtin_fabsf(a[c]));
+  }
+  if (total == 0u) return sum;
+  const float lim = far_limit(sum, mag);
+  __builtin_amdgcn_wave_barrier();  // (the previous block's reads are done)
+#pragma unroll
+  for (int c = 0; c < NT; c++) {
+    if (a[c] > kNegInf) buf[pos++] = a[c];
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t w0 = 0; w0 < total; w0 += 64u) {
+    const uint32_t cnt = min(64u, total - w0);
+    const float t = buf[w0 + lane];  // (past `total`: stale, masked below)
+    const unsigned long long far = __builtin_amdgcn_ballot_w64(lane < cnt && sure_far(t, lim));
+    uint32_t l = 0;
+    while (l < cnt) {
+      const unsigned long long stop = ~(far >> l);
+      const uint32_t e = l + (stop ? static_cast<uint32_t>(__builtin_ctzll(stop)) : 64u);
+      for (; l < e; l++) sum = lse_far(sum, lane_val(t, l));
+      if (l < cnt) {
+        sum = lse_u(sum, lane_val(t, l), P8);
+        l++;
+      }
+    }
+  }
+  return sum;
+}
 
 
 // ----------------------------------------------------------------------------
@@ -123,6 +179,7 @@ __device__ __forceinline__ void inside_chain_lat(const DeviceBatch& b, const Seq
   const float* __restrict__ zrm = q.m[CONTRA ? M_ZRM : M_ZRE];
   const float* __restrict__ qa = q.m[M_QA];
   const bool lane0 = lane == 0u;
+  __shared__ float steps[64];
   float zr = kNegInf, c = 0.f, mun = 0.f;
   if (!CONTRA) {
     // sums_rightmost_basepairs_external(i,j) = that of (i,j-1) extended by one step (344-351)
@@ -147,8 +204,8 @@ __device__ __forceinline__ void inside_chain_lat(const DeviceBatch& b, const Seq
           [&](const ABuf& B, uint32_t t0) {
             const uint32_t cnt = min(64u, d + 1u - t0);
             const float bx = pin(B.x);
-            for (uint32_t l = 0; l < cnt; l++)
-              zr = lse_u(zr, lane_val(bx, l) + Pc + Qc * static_cast<float>(d - t0 - l), P8);
+            const float a[1] = {lane < cnt ? bx + Pc + Qc * static_cast<float>(d - t0 - lane) : kNegInf};
+            zr = fold_block<1>(zr, a, steps, P8);
           });
       if (lane0) q.m[role == 0 ? M_ZRE : M_ZRM][od] = zr;
     }
@@ -179,18 +236,15 @@ __device__ __forceinline__ void inside_chain_lat(const DeviceBatch& b, const Seq
         },
         [&](const SBuf& B, uint32_t t0) {
           const uint32_t cnt = min(64u, d - t0);
-          const float bra = pin(B.ra), brb = pin(B.rb);
-          for (uint32_t l = 0; l < cnt; l++) {
-            const float ra = lane_val(bra, l);
-            float term;
-            if (!CONTRA) {
-              term = (role == 0) ? ra + lane_val(brb, l)
-                                 : (role == 1 ? ra + c : lane_val(brb, l) + (ra + c));
-            } else {
-              term = (role == 1) ? ra + mun * static_cast<float>(t0 + l) : lane_val(brb, l) + ra;
-            }
-            acc = lse_u(acc, term, P8);
+          const float ra = pin(B.ra), rb = pin(B.rb);
+          float a;  // the term of step t0 + lane
+          if (!CONTRA) {
+            a = (role == 0) ? ra + rb : (role == 1 ? ra + c : rb + (ra + c));
+          } else {
+            a = (role == 1) ? ra + mun * static_cast<float>(t0 + lane) : rb + ra;
           }
+          const float t[1] = {lane < cnt ? a : kNegInf};
+          acc = fold_block<1>(acc, t, steps, P8);
         });
   }
   if (lane0) {
@@ -347,6 +401,7 @@ __device__ __forceinline__ void outside_mb_lat(const DeviceBatch& b, const Seq& 
   // partners of base a as a 4-bit set: A:{U} C:{G} G:{C,U} U:{A,G}
   const uint32_t pairmask = (0x5A48u >> (4u * s[i])) & 15u;
   float pm = kNegInf, pm2 = kNegInf;
+  __shared__ float steps[64];
   // Blocks of 64 steps: lane l owns step t0 + l — it loads that step's two operands and
   // decides whether base k pairs with base i; a ballot gives the block's partner set, whose
   // members the chain then visits in ascending k through scalar bit scans and v_readlane.
@@ -370,24 +425,10 @@ __device__ __forceinline__ void outside_mb_lat(const DeviceBatch& b, const Seq& 
         const float a1 = bx + br;
         const float a2 = CONTRA ? bx + mun * static_cast<float>(t0 + lane - 1u) : bx;
         const bool has1 = B.has != 0u && t0 + lane >= 2u;  // (t = 1: only pm2 moves)
-        const float l1 = far_limit(pm), l2 = far_limit(pm2);
-        const unsigned long long f1 = __ballot(has1 && sure_far(a1, l1));
-        const unsigned long long f2 = __ballot(B.has != 0u && sure_far(a2, l2));
-        const unsigned long long g1 = __ballot(has1 && a1 > kNegInf) & ~f1;
-        const unsigned long long g2 = __ballot(B.has != 0u && a2 > kNegInf) & ~f2;
-        const unsigned long long ff = f1 & f2;
-        unsigned long long m = f1 | f2 | g1 | g2;
-        while (m) {
-          const uint32_t l = static_cast<uint32_t>(__builtin_ctzll(m));
-          m &= m - 1ull;
-          if (bit(ff, l)) {  // two independent two-instruction steps
-            pm = lse_far(pm, lane_val(a1, l));
-            pm2 = lse_far(pm2, lane_val(a2, l));
-          } else {
-            if (bit(f1 | g1, l)) pm = lse_u(pm, lane_val(a1, l), P8);
-            if (bit(f2 | g2, l)) pm2 = lse_u(pm2, lane_val(a2, l), P8);
-          }
-        }
+        const float t1[1] = {has1 ? a1 : kNegInf};
+        const float t2[1] = {B.has != 0u ? a2 : kNegInf};
+        pm = fold_block<1>(pm, t1, steps, P8);
+        pm2 = fold_block<1>(pm2, t2, steps, P8);
       });
   if (lane == 0u) reinterpret_cast<float2*>(q.m[M_PM])[col_off(j) + i] = make_float2(pm, pm2);
 }
@@ -418,6 +459,7 @@ __device__ __forceinline__ void outside_tail_lat(const DeviceBatch& b, const Seq
     float x;
     float2 yy;
   };
+  __shared__ float steps[192];
   // whole blocks of 64; a read past the cell's own rows stays inside the padded matrices
   // (always-fetch form: the number of loads in flight at the wait is static, so the wait for
   // this block's operands leaves the next block's loads in flight)
@@ -434,29 +476,9 @@ __device__ __forceinline__ void outside_tail_lat(const DeviceBatch& b, const Seq
         const float a0 = sa + by2 + bx;
         const float a1 = CONTRA ? sa + by + mun * static_cast<float>(i - (k0 + lane) - 1) : sa + by;
         const float a2 = sa + bx + by;
-        const float lim = far_limit(p);
         const bool in = lane < cnt;
-        const unsigned long long f0 = __ballot(in && sure_far(a0, lim));
-        const unsigned long long f1 = __ballot(in && sure_far(a1, lim));
-        const unsigned long long f2 = __ballot(in && sure_far(a2, lim));
-        const unsigned long long n0 = __ballot(in && a0 > kNegInf);  // (far ones included)
-        const unsigned long long n1 = __ballot(in && a1 > kNegInf);
-        const unsigned long long n2 = __ballot(in && a2 > kNegInf);
-        const unsigned long long ff = f0 & f1 & f2;
-        unsigned long long m = n0 | n1 | n2;
-        while (m) {
-          const uint32_t l = static_cast<uint32_t>(__builtin_ctzll(m));
-          m &= m - 1ull;
-          if (bit(ff, l)) {
-            p = lse_far(p, lane_val(a0, l));
-            p = lse_far(p, lane_val(a1, l));
-            p = lse_far(p, lane_val(a2, l));
-          } else {
-            if (bit(n0, l)) p = lse_u(p, lane_val(a0, l), P8);
-            if (bit(n1, l)) p = lse_u(p, lane_val(a1, l), P8);
-            if (bit(n2, l)) p = lse_u(p, lane_val(a2, l), P8);
-          }
-        }
+        const float a[3] = {in ? a0 : kNegInf, in ? a1 : kNegInf, in ? a2 : kNegInf};
+        p = fold_block<3>(p, a, steps, P8);
       });
   if (i >= 1) {
     // k = i - 1: the interval [k+1, i-1] is empty, only the middle term exists
@@ -489,6 +511,7 @@ __device__ __forceinline__ void inside_pair_lat(const DeviceBatch& b, const Seq&
   const auto model = ModelOf<CONTRA>::make(b);
   const uint32_t o = tri_off(n, d) + i;
   const float* __restrict__ qb = q.m[M_QB];
+  __shared__ float steps[64];
   float sum = kNegInf;
   if (!CONTRA || d - 1 <= RNAMC_MAX_LOOP_LEN) sum = lse_u(sum, model.hairpin(s, n, i, j), P8);
   if (d >= 3) {
@@ -507,13 +530,8 @@ __device__ __forceinline__ void inside_pair_lat(const DeviceBatch& b, const Seq&
     float cur = row_term(0u);
     for (uint32_t a = 0; a <= lim; a++) {
       const float nxt = row_term(a + 1u);  // (all -inf past the last row)
-      const float t = pin(cur);
-      unsigned long long m = __ballot(t > kNegInf);
-      while (m) {
-        const uint32_t l = static_cast<uint32_t>(__builtin_ctzll(m));
-        m &= m - 1ull;
-        sum = lse_u(sum, lane_val(t, l), P8);
-      }
+      const float t[1] = {pin(cur)};
+      sum = fold_block<1>(sum, t, steps, P8);
       cur = nxt;
     }
   }
@@ -551,6 +569,7 @@ __device__ __forceinline__ void outside_head_lat(const DeviceBatch& b, const Seq
   const float zr = (j > n - 2) ? 0.f : z[tri_off(n, n - 2 - j) + j + 1];  // Z[j+1][n-1]
   float p = CONTRA ? zl + zr + qa_ij + b.params->contra.external_score_basepair - ztot
                    : zl + qa_ij + zr - ztot;
+  __shared__ float steps[64];
   if (d + 2 < n) {
     // enclosing pairs (k,l) = (i-1-a, j+1+bb), a ascending (k descending), bb ascending,
     // a + bb <= 30, k >= 0, l <= n-1
@@ -568,13 +587,8 @@ __device__ __forceinline__ void outside_head_lat(const DeviceBatch& b, const Seq
     float cur = row_term(0u);
     for (uint32_t a = 0; a <= lim; a++) {
       const float nxt = row_term(a + 1u);
-      const float t = pin(cur);
-      unsigned long long m = __ballot(t > kNegInf);
-      while (m) {
-        const uint32_t l = static_cast<uint32_t>(__builtin_ctzll(m));
-        m &= m - 1ull;
-        p = lse_u(p, lane_val(t, l), P8);
-      }
+      const float t[1] = {pin(cur)};
+      p = fold_block<1>(p, t, steps, P8);
       cur = nxt;
     }
   }

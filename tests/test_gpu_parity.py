@@ -668,17 +668,22 @@ def test_latency_forms_bit_exact(params, contra, short):
         ctx.set("lat_inside", 2)          # eight chains per wave, 8-lane speculative logsumexp
         ctx.set("lat_pairs", 1)
         lat4, logz5 = ctx.bpp_batch(seqs, contra, short)
+        ctx.set("lat_inside", 3)          # both: wave per chain below 300 chains, else eight per wave
+        ctx.set("lat_e_waves", 200)       # (and the three-lanes form above 200 waves)
+        lat5, logz6 = ctx.bpp_batch(seqs, contra, short)
+        ctx.set("lat_e_waves", 2048)
+        ctx.set("lat_inside_waves", 2048)
         ctx.set("latency_mode", 1)    # default: a lone sequence takes the latency forms
         one, logz3 = ctx.bpp_batch([seqs[-4]], contra, short)
     finally:
         ctx.close()
     ref, ref_logz = O.bpp_batch(params.ptr, seqs, contra, short, n_threads=16)
-    for s, a, m, m2, m3, m4, r in zip(seqs, base, lat, lat2, lat3, lat4, ref):
-        for got in (m, m2, m3, m4):
+    for s, a, m, m2, m3, m4, m5, r in zip(seqs, base, lat, lat2, lat3, lat4, lat5, ref):
+        for got in (m, m2, m3, m4, m5):
             assert np.array_equal(np.asarray(a.packed).view(np.uint32),
                                   np.asarray(got.packed).view(np.uint32)), f"n={len(s)}"
         assert_same(m.packed, r, f"n={len(s)}")
-    for lz in (logz0, logz1, logz2, logz4, logz5):
+    for lz in (logz0, logz1, logz2, logz4, logz5, logz6):
         assert np.array_equal(np.asarray(lz).view(np.uint32), np.asarray(ref_logz).view(np.uint32))
     assert_same(one[0].packed, ref[-4], "lone sequence")
     assert np.float32(logz3[0]).view(np.uint32) == np.float32(ref_logz[-4]).view(np.uint32)
