@@ -117,11 +117,24 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {  // set 
                                    __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
 }
 
+// N sure-far steps of the walking sum (fold_block): lane l takes the sum of lane l-1 through
+// the DPP operand of its subtraction.
+template <int N>
+__device__ __forceinline__ float far_steps(float s, float t) {
+#pragma unroll
+  for (int u = 0; u < N; u++) {
+    const float prev = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_update_dpp(
+        0, static_cast<int>(__float_as_uint(s)), 0x13C /* wave_ror:1 */, 0xF, 0xF, false)));
+    const float z = prev - t;
+    s = t + z;
+  }
+  return s;
+}
+
 // One block of a chain whose steps come NT per lane (lane l: steps NT*l .. NT*l + NT-1, a
 // term of -inf = no step).  The finite terms are compacted in step order through LDS
 // (`buf`: 64 * NT floats of this wave's own), classified against the sum at block start,
-// and the chain then alternates between runs of sure-far steps — a loop of one lane read
-// and the two instructions of lse_far per step — and single general steps.
+// and the chain then alternates between runs of sure-far steps and single general steps.
 template <int NT>
 __device__ __forceinline__ float fold_block(float sum, const float (&a)[NT], float* buf,
                                             const Piece8& P8) {
@@ -143,20 +156,37 @@ __device__ __forceinline__ float fold_block(float sum, const float (&a)[NT], flo
     if (a[c] > kNegInf) buf[pos++] = a[c];
   }
   __builtin_amdgcn_wave_barrier();
+  // A lone wave issues one instruction every ~6.7 cycles whatever its kind
+  // (scripts/ubench/far_step.hip), so the chain is laid out for the fewest instructions per
+  // step: the running sum WALKS across the lanes.  Step l happens in lane l, which takes the
+  // sum from lane l-1 through the DPP operand of its subtraction (wave_ror:1; lane 0 reads
+  // lane 63, where the block's incoming sum still stands) — a sure-far step is two VALU
+  // instructions and no lane read.  The other lanes compute values nobody uses.  A general
+  // step fetches sum and term into SGPRs, runs lse_u as before and leaves its result in
+  // every lane.
   for (uint32_t w0 = 0; w0 < total; w0 += 64u) {
     const uint32_t cnt = min(64u, total - w0);
     const float t = buf[w0 + lane];  // (past `total`: stale, masked below)
     const unsigned long long far = __builtin_amdgcn_ballot_w64(lane < cnt && sure_far(t, lim));
+    float s = sum;  // uniform here
     uint32_t l = 0;
     while (l < cnt) {
+      // the run of sure-far steps from l on (bits past cnt are clear), in straight-line
+      // pieces of 16, 8, 4, 2, 1 steps: ~2 instructions per step and a dozen per run
       const unsigned long long stop = ~(far >> l);
-      const uint32_t e = l + (stop ? static_cast<uint32_t>(__builtin_ctzll(stop)) : 64u);
-      for (; l < e; l++) sum = lse_far(sum, lane_val(t, l));
+      uint32_t r = stop ? static_cast<uint32_t>(__builtin_ctzll(stop)) : 64u;
+      l += r;
+      for (; r >= 16u; r -= 16u) s = far_steps<16>(s, t);
+      if (r & 8u) s = far_steps<8>(s, t);
+      if (r & 4u) s = far_steps<4>(s, t);
+      if (r & 2u) s = far_steps<2>(s, t);
+      if (r & 1u) s = far_steps<1>(s, t);
       if (l < cnt) {
-        sum = lse_u(sum, lane_val(t, l), P8);
+        s = lse_u(lane_val(s, (l + 63u) & 63u), lane_val(t, l), P8);
         l++;
       }
     }
+    sum = lane_val(s, cnt - 1u);
   }
   return sum;
 }
