@@ -94,7 +94,10 @@ struct rnamc_ctx {
   int64_t lat_inside = 2;
   int64_t lat_inside_waves = 2048;
   int64_t lat_e_waves = 2048;
+  // debug: probs_multibranch and the pair-probability chains as two launches (timing splits)
   int64_t lat_split = 0;
+  // one launch per diagonal in a latency-form group (chains + 2-loop blocks), no second stream
+  int64_t lat_merge = 1;
   int64_t lat_pairs = 1;   // its 2-loop blocks run one wave per listed cell (both sweeps)
   int64_t head_wmax_in = 448, head_wmax_out = 448;
   // role mask of timing experiments (bit0 folds, 1 pair block, 2 mb, 3 pair probs); settable
@@ -378,7 +381,22 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
         need_pairs(d);  // (only the first diagonal finds work here)
         const bool pair_next = heads_done < static_cast<int64_t>(d) + 1 && d + 1 < gmax;
         const uint32_t pv = (d + ring - 1) % ring, cu = d % ring;
-        if (pair_next && do_pair) {
+        // One wave per chain while the launch's 3 x cells chains leave every chain wave
+        // (nearly) a SIMD of its own, the three-lanes-per-cell form before that.  The
+        // wave forms complete sums_1ormore_basepairs of diagonal d-1 in the launch
+        // of diagonal d (sequences that end at d-1 included).
+        const uint64_t chains = 3ull * (gmax - d) * active(d);
+        // lat_inside bit 0: one wave per chain on the diagonals with few chains; bit 1: eight
+        // chains per wave on the diagonals with few enough waves
+        const int form = !do_sums ? 0
+                         : ((c->lat_inside & 1) && chains <= static_cast<uint64_t>(c->lat_inside_waves)) ? 1
+                         : ((c->lat_inside & 2) && (chains + 7) / 8 <= static_cast<uint64_t>(c->lat_e_waves)) ? 2 : 0;
+        const bool wave_form = form != 0;
+        // the closing-pair blocks of diagonal d+1 ride in the same launch as the wave-form
+        // chains of diagonal d (one launch per diagonal, no cross-stream events: ~12 us per
+        // diagonal less than the two-stream schedule, profiles/r02_latency_forms.txt)
+        const bool merged = wave_form && c->lat_pairs != 0 && c->lat_merge != 0;
+        if (pair_next && do_pair && !merged) {
           if (!have_a) {  // everything so far is on `st`
             HIPCHK(hipEventRecord(c->ev_a[pv], st));
             have_a = true;
@@ -393,18 +411,9 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
         }
         if (have_b) HIPCHK(hipStreamWaitEvent(st, c->ev_b[pv], 0));
         if (do_sums) {
-          // One wave per fold chain while the launch's 3 x cells chains leave every chain wave
-          // (nearly) a SIMD of its own, the three-lanes-per-cell form before that.  The
-          // wave-per-chain form completes sums_1ormore_basepairs of diagonal d-1 in the launch
-          // of diagonal d (sequences that end at d-1 included).
-          const uint64_t chains = 3ull * (gmax - d) * active(d);
-          // lat_inside bit 0: one wave per chain on the diagonals with few chains; bit 1: eight
-          // chains per wave on the diagonals with few enough waves
-          const int form = ((c->lat_inside & 1) && chains <= static_cast<uint64_t>(c->lat_inside_waves)) ? 1
-                           : ((c->lat_inside & 2) && (chains + 7) / 8 <= static_cast<uint64_t>(c->lat_e_waves)) ? 2 : 0;
-          const bool wave_form = form != 0;
+          const uint32_t pair_d = (merged && pair_next && do_pair) ? d + 1 : 0;
           if (wave_form || combine_due) {
-            launch_inside_lat(b, contra, d, gmax, active(d >= 1 ? d - 1 : 0), form, combine_due, st);
+            launch_inside_lat(b, contra, d, gmax, active(d >= 1 ? d - 1 : 0), form, combine_due, pair_d, st);
             c->stats.launches_inside++;
           }
           if (!wave_form) {
@@ -413,11 +422,15 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
           }
           combine_due = wave_form;
         }
-        HIPCHK(hipEventRecord(c->ev_a[cu], st));
-        have_a = true;
+        if (merged) {
+          have_a = false;  // (recorded when a later diagonal needs it)
+        } else {
+          HIPCHK(hipEventRecord(c->ev_a[cu], st));
+          have_a = true;
+        }
         if (pair_next) {
-          HIPCHK(hipEventRecord(c->ev_b[cu], c->aux_stream));
-          have_b = true;
+          if (!merged) HIPCHK(hipEventRecord(c->ev_b[cu], c->aux_stream));
+          have_b = !merged;
           pairs_done = heads_done = d + 1;
         } else {
           have_b = false;
@@ -425,7 +438,7 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
       }
       if (have_b) HIPCHK(hipStreamWaitEvent(st, c->ev_b[(gmax - 1) % ring], 0));
       if (combine_due)  // combine of the last diagonal
-        launch_inside_lat(b, contra, gmax, gmax, active(gmax - 1), 0, true, st);
+        launch_inside_lat(b, contra, gmax, gmax, active(gmax - 1), 0, true, 0, st);
     }
     for (uint32_t d = dmin_in; d < gmax && !lat_in;) {
       const bool fuse = c->fuse_inside != 0 && d >= 2 && d + 1 < gmax &&
@@ -512,8 +525,19 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
         // latency-form group: {probs_multibranch, multibranch half of the pair probabilities}
         // of diagonal d on `st` (k_outside_lat) beside the 2-loop half of diagonal d-1 on
         // aux_stream; both need both of diagonal d+1
+        // (lat_merge: both in ONE launch on `st`, no events)
+        const bool merged = c->lat_pairs != 0 && c->lat_merge != 0 && c->lat_split == 0;
         bool first = true;
-        for (uint32_t d = gmax + 1; d-- > dmin_out;) {
+        for (uint32_t d = gmax + 1; d-- > dmin_out && merged;) {
+          const bool head = d >= 1 && d - 1 >= dmin_out && r_head;
+          if (d < gmax || head) {
+            timed(0, st, [&]() {
+              launch_outside_lat(b, contra, d, gmax, active(d >= 1 ? d - 1 : 0), r_mb, r_tail, head, st);
+            });
+            c->stats.launches_outside++;
+          }
+        }
+        for (uint32_t d = gmax + 1; d-- > dmin_out && !merged;) {
           const bool head = d >= 1 && d - 1 >= dmin_out;
           const uint32_t na = active(d >= 1 ? d - 1 : 0);
           const uint32_t pv = (d + 1) % ring, cu = d % ring;
@@ -525,10 +549,11 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
           HIPCHK(hipStreamWaitEvent(c->aux_stream, c->ev_a[pv], 0));
           if (d < gmax) {
             if (c->lat_split != 0) {
-              timed(1, st, [&]() { launch_outside_lat(b, contra, d, gmax, active(d), r_mb, false, st); });
-              timed(0, st, [&]() { launch_outside_lat(b, contra, d, gmax, active(d), false, r_tail, st); });
-            } else
-            timed(0, st, [&]() { launch_outside_lat(b, contra, d, gmax, active(d), r_mb, r_tail, st); });
+              timed(1, st, [&]() { launch_outside_lat(b, contra, d, gmax, active(d), r_mb, false, false, st); });
+              timed(0, st, [&]() { launch_outside_lat(b, contra, d, gmax, active(d), false, r_tail, false, st); });
+            } else {
+              timed(0, st, [&]() { launch_outside_lat(b, contra, d, gmax, active(d), r_mb, r_tail, false, st); });
+            }
             c->stats.launches_outside++;
           }
           HIPCHK(hipEventRecord(c->ev_a[cu], st));
@@ -876,6 +901,8 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     c->lat_inside_waves = value;
   } else if (k == "lat_split") {
     c->lat_split = value;
+  } else if (k == "lat_merge") {
+    c->lat_merge = value;
   } else if (k == "lat_e_waves" && value >= 0) {
     c->lat_e_waves = value;
   } else if (k == "lat_pairs") {

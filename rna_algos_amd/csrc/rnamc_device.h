@@ -59,10 +59,12 @@ int launch_head_carry(const DeviceBatch& b, bool contra, bool outside, uint32_t 
 // Latency forms for groups too small to fill the chip (rnamc_latency.h): one wave per fold
 // chain.  A group that uses them uses them on EVERY diagonal (they keep W dense, and complete
 // sums_1ormore_basepairs of diagonal d-1 in the launch of diagonal d).
+// pair_d != 0: the closing-pair blocks of diagonal pair_d in the same launch; head: the 2-loop
+// half of the pair probabilities of diagonal d - 1 in the same launch
 void launch_inside_lat(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
-                       int form, bool do_combine, hipStream_t st);
+                       int form, bool do_combine, uint32_t pair_d, hipStream_t st);
 void launch_outside_lat(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
-                        bool do_mb, bool do_tail, hipStream_t st);
+                        bool do_mb, bool do_tail, bool head, hipStream_t st);
 // closing-pair block (inside) / 2-loop half of the pair probabilities (outside) of diagonal d
 void launch_pair_lat(const DeviceBatch& b, bool contra, bool outside, uint32_t d, uint32_t max_n,
                      uint32_t nseq, hipStream_t st);

@@ -1487,14 +1487,27 @@ __global__ void __launch_bounds__(kHeadBlock)
 // Latency-form launches, one wave per workgroup (rnamc_latency.h).
 // Inside, diagonal d: blocks [0, 3 cells) one (cell, role) chain each; then one lane per cell of
 // diagonal d-1 for the combine that completes sums_1ormore_basepairs (do_combine).
+// With pair_cells != 0 the launch opens with one block per cell of diagonal pair_d for its
+// closing-pair blocks (what k_pair_lat would run beside this launch on a second stream: they
+// need nothing newer than diagonal d-1 either).
 template <bool CONTRA>
 __global__ void __launch_bounds__(64) k_inside_lat(DeviceBatch b, uint32_t d, uint32_t cells_max,
-                                                   uint32_t nseq, int form, int do_combine) {
+                                                   uint32_t nseq, int form, int do_combine,
+                                                   uint32_t pair_d, uint32_t pair_cells) {
   __shared__ LseTab tabs;
-  const uint32_t bx = blockIdx.x / nseq;
+  uint32_t bx = blockIdx.x / nseq;
   const uint32_t which = blockIdx.x - bx * nseq;
   const Seq q = load_seq(b, which);
   const uint32_t n = q.n;
+  if (bx < pair_cells) {
+    if (pair_d >= n) return;
+    const uint32_t cnt = q.ccnt[pair_d];
+    if (bx >= cnt) return;
+    const uint32_t i = uni(static_cast<uint32_t>(q.cidx[tri_off(n, pair_d) + bx]));
+    inside_pair_lat<CONTRA, PAIR_FULL>(b, q, pair_d, i, load_piece8());
+    return;
+  }
+  bx -= pair_cells;
   // form 1: one wave per (cell, role); form 2: eight cells of one role per wave; 0: no chains
   const uint32_t per = form == 2 ? 8u : 1u;
   const uint32_t wpr = (cells_max + per - 1u) / per;  // waves per role
@@ -1523,15 +1536,28 @@ __global__ void __launch_bounds__(64) k_inside_lat(DeviceBatch b, uint32_t d, ui
 // Outside, diagonal d: blocks [0, cells): multibranch half of the pair probability of one
 // listed cell each, longest chains (largest i) first; then one block per cell for
 // probs_multibranch{,2}.
+// With head_cells != 0 the launch also holds one block per cell of diagonal head_d (= d - 1)
+// for the 2-loop half of its pair probabilities (k_pair_lat<., true>'s work: it needs both
+// halves of diagonal d + 1 and beyond, like everything else in this launch).
 template <bool CONTRA>
 __global__ void __launch_bounds__(64) k_outside_lat(DeviceBatch b, uint32_t d, uint32_t cells_max,
-                                                    uint32_t nseq, int do_mb, int do_tail) {
-  const uint32_t bx = blockIdx.x / nseq;
+                                                    uint32_t nseq, int do_mb, int do_tail,
+                                                    uint32_t head_d, uint32_t head_cells) {
+  uint32_t bx = blockIdx.x / nseq;
   const uint32_t which = blockIdx.x - bx * nseq;
   const Seq q = load_seq(b, which);
   const uint32_t n = q.n;
-  if (d >= n) return;
   const Piece8 P8 = load_piece8();
+  if (bx >= 2u * cells_max) {  // after the chains of diagonal d
+    bx -= 2u * cells_max;
+    if (bx >= head_cells || head_d >= n) return;
+    const uint32_t cnt = q.ccnt[head_d];
+    if (bx >= cnt) return;
+    const uint32_t i = uni(static_cast<uint32_t>(q.cidx[tri_off(n, head_d) + bx]));
+    outside_head_lat<CONTRA>(b, q, head_d, i, P8);
+    return;
+  }
+  if (d >= n) return;
   if (bx < cells_max) {
     if (!do_tail) return;
     const uint32_t cnt = q.ccnt[d];
@@ -1885,35 +1911,41 @@ void launch_outside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_
 // 2: eight chains per wave, 0: none) and the combine that completes sums_1ormore_basepairs of
 // diagonal d-1 (do_combine)
 void launch_inside_lat(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
-                       int form, bool do_combine, hipStream_t st) {
+                       int form, bool do_combine, uint32_t pair_d, hipStream_t st) {
   if (nseq == 0) return;
   const uint32_t cells = (form && d < max_n) ? max_n - d : 0;
   const uint32_t per = form == 2 ? 8u : 1u;
   const uint32_t waves = 3u * ((cells + per - 1u) / per);
   const uint32_t cb = (do_combine && d >= 1 && d - 1 < max_n) ? (max_n - d + 1 + 63) / 64 : 0;
-  if (waves + cb == 0) return;
-  const dim3 g((waves + cb) * nseq, 1, 1);
+  const uint32_t pc = (pair_d != 0 && pair_d < max_n) ? max_n - pair_d : 0;  // pair_d 0: none
+  if (waves + cb + pc == 0) return;
+  const dim3 g((pc + waves + cb) * nseq, 1, 1);
   const int a1 = do_combine ? 1 : 0;
   if (contra) {
-    hipLaunchKernelGGL(k_inside_lat<true>, g, dim3(64), 0, st, b, d, cells, nseq, cells ? form : 0, a1);
+    hipLaunchKernelGGL(k_inside_lat<true>, g, dim3(64), 0, st, b, d, cells, nseq, cells ? form : 0, a1,
+                       pair_d, pc);
   } else {
-    hipLaunchKernelGGL(k_inside_lat<false>, g, dim3(64), 0, st, b, d, cells, nseq, cells ? form : 0, a1);
+    hipLaunchKernelGGL(k_inside_lat<false>, g, dim3(64), 0, st, b, d, cells, nseq, cells ? form : 0, a1,
+                       pair_d, pc);
   }
 }
 
 // probs_multibranch{,2} and the multibranch half of the pair probabilities of diagonal d, one
 // wave per cell / listed cell
+// (head: with the 2-loop half of the pair probabilities of diagonal d - 1 in the same launch)
 void launch_outside_lat(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
-                        bool do_mb, bool do_tail, hipStream_t st) {
-  if (d >= max_n || nseq == 0) return;
-  const uint32_t cells = max_n - d;
-  const dim3 g(2 * cells * nseq, 1, 1);
+                        bool do_mb, bool do_tail, bool head, hipStream_t st) {
+  if (nseq == 0) return;
+  const uint32_t cells = d < max_n ? max_n - d : 0;
+  const uint32_t head_d = d >= 1 ? d - 1 : 0;
+  const uint32_t hc = (head && d >= 1 && head_d < max_n) ? max_n - head_d : 0;
+  if (cells + hc == 0) return;
+  const dim3 g((2 * cells + hc) * nseq, 1, 1);
   const int a0 = do_mb ? 1 : 0, a1 = do_tail ? 1 : 0;
-  const size_t lds_cap = 0;
   if (contra) {
-    hipLaunchKernelGGL(k_outside_lat<true>, g, dim3(64), lds_cap, st, b, d, cells, nseq, a0, a1);
+    hipLaunchKernelGGL(k_outside_lat<true>, g, dim3(64), 0, st, b, d, cells, nseq, a0, a1, head_d, hc);
   } else {
-    hipLaunchKernelGGL(k_outside_lat<false>, g, dim3(64), lds_cap, st, b, d, cells, nseq, a0, a1);
+    hipLaunchKernelGGL(k_outside_lat<false>, g, dim3(64), 0, st, b, d, cells, nseq, a0, a1, head_d, hc);
   }
 }
 

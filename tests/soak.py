@@ -42,6 +42,7 @@ def main():
             # round 2: latency forms and the optional 2-loop kernels
             "latency_mode": int(rng.choice([0, 1, 1, 2])),
             "lat_pairs": int(rng.integers(0, 2)),
+            "lat_merge": int(rng.integers(0, 2)),
             "lat_inside": int(rng.integers(0, 4)),
             "lat_e_waves": int(rng.choice([0, 64, 2048, 1 << 20])),
             "lat_inside_waves": int(rng.choice([0, 300, 2048, 1 << 20])),

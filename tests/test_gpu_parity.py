@@ -667,7 +667,9 @@ def test_latency_forms_bit_exact(params, contra, short):
         lat3, logz4 = ctx.bpp_batch(seqs, contra, short)
         ctx.set("lat_inside", 2)          # eight chains per wave, 8-lane speculative logsumexp
         ctx.set("lat_pairs", 1)
+        ctx.set("lat_merge", 0)           # (2-loop blocks beside the chains on a second stream)
         lat4, logz5 = ctx.bpp_batch(seqs, contra, short)
+        ctx.set("lat_merge", 1)
         ctx.set("lat_inside", 3)          # both: wave per chain below 300 chains, else eight per wave
         ctx.set("lat_e_waves", 200)       # (and the three-lanes form above 200 waves)
         lat5, logz6 = ctx.bpp_batch(seqs, contra, short)
