@@ -689,3 +689,41 @@ def test_latency_forms_bit_exact(params, contra, short):
         assert np.array_equal(np.asarray(lz).view(np.uint32), np.asarray(ref_logz).view(np.uint32))
     assert_same(one[0].packed, ref[-4], "lone sequence")
     assert np.float32(logz3[0]).view(np.uint32) == np.float32(ref_logz[-4]).view(np.uint32)
+
+
+@pytest.mark.parametrize("scale", [40.0, 700.0, 20000.0])
+@pytest.mark.parametrize("contra", [False, True])
+def test_latency_forms_large_magnitudes(scale, contra):
+    """The ahead-of-chain classification of rnamc_latency.h keeps a margin that grows with
+    the magnitudes of sum and terms (1 below 2^12, 4 below 2^16, 64 below 2^20, off beyond):
+    tables scaled so that the sums of a ~200-nt sequence reach each tier.  Probabilities
+    underflow to 0 or saturate at such scales, so the LOG-domain matrices are compared."""
+    from rna_algos_amd.mccaskill_algo import Context
+    from rna_algos_amd.utils import FoldScoreSets
+    P = FoldScoreSets.synthetic(7)
+    for name, (off, cnt) in P._fields.items():
+        P._buf[off:off + 4 * cnt].view(np.float32)[:] *= np.float32(scale)
+    rng = np.random.default_rng(int(scale))
+    ctx = Context(P, device=0)
+    try:
+        ctx.set("latency_mode", 2)
+        for n in (211, 97):
+            seq = rng.integers(0, 4, n).astype(np.uint8)
+            got, logz = ctx.bpp_batch([seq], contra, False)
+            # sums_close .. mbclose everywhere; probs_multibranch{,2} where the reference has an
+            # entry (the latency forms also fill cells the reference never visits or reads)
+            _, _, mats = O.bpp_dump(P.ptr, seq, contra, False)
+            iu = np.triu_indices(n)
+            for w in range(7):
+                g, r = ctx.debug_fetch(0, w, n)[iu], mats[w][iu]
+                same = (g.view(np.uint32) == r.view(np.uint32)) | (np.isnan(g) & np.isnan(r))
+                if w >= 5:
+                    same |= ~np.isfinite(r)
+                    assert np.isfinite(r).sum() > n
+                assert same.all(), f"scale={scale} n={n} matrix {w}: {(~same).sum()} entries differ"
+            ref, ref_logz = O.bpp_batch(P.ptr, [seq], contra, False, n_threads=1)
+            assert abs(float(ref_logz[0])) > scale * n / 8  # the tier this case is meant for
+            assert_same(got[0].packed, ref[0], f"scale={scale} n={n}")
+            assert np.float32(logz[0]).view(np.uint32) == np.float32(ref_logz[0]).view(np.uint32)
+    finally:
+        ctx.close()
