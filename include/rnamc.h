@@ -218,7 +218,7 @@ int rnamc_ctx_set_params(rnamc_ctx* ctx, const rnamc_params* params);
 /* Tuning knobs (all optional): name in {"group_max_seqs","group_max_nt","group_ws_bytes",
  * "block_threads","fuse_inside","dual_outside","dual_min_cells","dual_max_diag",
  * "order_inside","order_outside","head_lds","head_wmax_in","head_wmax_out","latency_mode",
- * "lat_max_cells","lat_inside","lat_inside_waves","lat_e_waves","lat_pairs","lat_merge","profile"}; returns RNAMC_ERR_INVALID_ARG for unknown names. */
+ * "lat_max_cells","lat_inside","lat_inside_waves","lat_e_waves","lat_pairs","lat_merge","lat_zr_ahead","profile"}; returns RNAMC_ERR_INVALID_ARG for unknown names. */
 int rnamc_ctx_set(rnamc_ctx* ctx, const char* name, int64_t value);
 
 /* mccaskill_algo over a batch (src/mccaskill_algo.rs:247-280 for each record, as

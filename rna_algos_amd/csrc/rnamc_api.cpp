@@ -98,6 +98,8 @@ struct rnamc_ctx {
   int64_t lat_split = 0;
   // one launch per diagonal in a latency-form group (chains + 2-loop blocks), no second stream
   int64_t lat_merge = 1;
+  // CONTRAfold, eight-chains form: the sums_rightmost_basepairs folds run one launch ahead
+  int64_t lat_zr_ahead = 1;
   int64_t lat_pairs = 1;   // its 2-loop blocks run one wave per listed cell (both sweeps)
   int64_t head_wmax_in = 448, head_wmax_out = 448;
   // role mask of timing experiments (bit0 folds, 1 pair block, 2 mb, 3 pair probs); settable
@@ -376,7 +378,7 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
                       static_cast<uint64_t>(nseq) * gmax <= static_cast<uint64_t>(c->lat_max_cells));
     const bool lat_in = lat && (c->lat_inside != 0 || c->lat_pairs != 0);
     if (lat_in) {
-      bool have_a = false, have_b = false, combine_due = false;
+      bool have_a = false, have_b = false, combine_due = false, zr_parked = false;
       for (uint32_t d = dmin_in; d < gmax; d++) {
         need_pairs(d);  // (only the first diagonal finds work here)
         const bool pair_next = heads_done < static_cast<int64_t>(d) + 1 && d + 1 < gmax;
@@ -386,12 +388,20 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
         // wave forms complete sums_1ormore_basepairs of diagonal d-1 in the launch
         // of diagonal d (sequences that end at d-1 included).
         const uint64_t chains = 3ull * (gmax - d) * active(d);
+        // (CONTRAfold, eight-chains form: two more chain kinds per cell, see lat_zr_ahead)
+        const uint64_t kinds_e = (contra && c->lat_zr_ahead != 0) ? 5 : 3;
         // lat_inside bit 0: one wave per chain on the diagonals with few chains; bit 1: eight
         // chains per wave on the diagonals with few enough waves
         const int form = !do_sums ? 0
                          : ((c->lat_inside & 1) && chains <= static_cast<uint64_t>(c->lat_inside_waves)) ? 1
-                         : ((c->lat_inside & 2) && (chains + 7) / 8 <= static_cast<uint64_t>(c->lat_e_waves)) ? 2 : 0;
+                         : ((c->lat_inside & 2) && (chains / 3 * kinds_e + 7) / 8 <= static_cast<uint64_t>(c->lat_e_waves)) ? 2 : 0;
         const bool wave_form = form != 0;
+        // CONTRAfold: a cell's sums_rightmost_basepairs folds (d steps) precede its other
+        // folds (d steps more); all but their last step needs nothing of diagonal d, so the
+        // eight-chains launch of diagonal d-1 runs them ahead (flag 4: do so for d+1, flag 8:
+        // this diagonal's were parked)
+        const bool zr_ahead = form == 2 && kinds_e == 5;
+        const int form_arg = form | (zr_ahead ? 4 : 0) | (form == 2 && zr_parked ? 8 : 0);
         // the closing-pair blocks of diagonal d+1 ride in the same launch as the wave-form
         // chains of diagonal d (one launch per diagonal, no cross-stream events: ~12 us per
         // diagonal less than the two-stream schedule, profiles/r02_latency_forms.txt)
@@ -413,7 +423,7 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
         if (do_sums) {
           const uint32_t pair_d = (merged && pair_next && do_pair) ? d + 1 : 0;
           if (wave_form || combine_due) {
-            launch_inside_lat(b, contra, d, gmax, active(d >= 1 ? d - 1 : 0), form, combine_due, pair_d, st);
+            launch_inside_lat(b, contra, d, gmax, active(d >= 1 ? d - 1 : 0), form_arg, combine_due, pair_d, st);
             c->stats.launches_inside++;
           }
           if (!wave_form) {
@@ -422,6 +432,7 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
           }
           combine_due = wave_form;
         }
+        zr_parked = zr_ahead;
         if (merged) {
           have_a = false;  // (recorded when a later diagonal needs it)
         } else {
@@ -903,6 +914,8 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     c->lat_split = value;
   } else if (k == "lat_merge") {
     c->lat_merge = value;
+  } else if (k == "lat_zr_ahead") {
+    c->lat_zr_ahead = value;
   } else if (k == "lat_e_waves" && value >= 0) {
     c->lat_e_waves = value;
   } else if (k == "lat_pairs") {

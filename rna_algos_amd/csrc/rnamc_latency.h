@@ -312,16 +312,23 @@ constexpr int kUE = 16;  // fold steps per operand buffer (two buffers)
 // became a handful of scalar branches in every fold step)
 template <bool CONTRA, uint32_t ROLE>
 __device__ __forceinline__ void inside_chain_e(const DeviceBatch& b, const Seq& q, uint32_t d,
-                                               uint32_t cell0, const Piece8& P8) {
+                                               uint32_t cell0, const Piece8& P8, bool zr_parked) {
   constexpr uint32_t role = ROLE;
   const uint32_t n = q.n;
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t cells = n - d;
+  // roles 3, 4 (CONTRAfold): all but the last step of sums_rightmost_basepairs_{external,
+  // multibranch} of diagonal d + 1 — they need sums_accessible of diagonals <= d only, so the
+  // two dependent chains of a CONTRAfold cell (468-486, then 487-512) overlap across launches
+  constexpr bool AHEAD = ROLE >= 3;
+  const uint32_t D = AHEAD ? d + 1u : d;  // the diagonal this wave's cells lie on
+  if (D >= n) return;
+  const uint32_t cells = n - D;
   const uint32_t ic = cell0 + (lane >> 3);
+  if (cell0 >= cells) return;
   const bool valid = ic < cells;
   const uint32_t i = valid ? ic : cells - 1u;  // groups past the diagonal shadow its last cell
   const bool leader = valid && (lane & 7u) == 0u;
-  const uint32_t od = tri_off(n, d) + i;
+  const uint32_t od = tri_off(n, D) + i;
   const float* __restrict__ zre = q.m[M_ZRE];
   const float* __restrict__ zrm = q.m[CONTRA ? M_ZRM : M_ZRE];
   const float* __restrict__ qa = q.m[M_QA];
@@ -334,26 +341,35 @@ __device__ __forceinline__ void inside_chain_e(const DeviceBatch& b, const Seq& 
   } else {
     const rnamc_fold_score_sets& f = b.params->contra;
     mun = f.multibranch_score_unpair;
-    if (role < 2) {
-      const float Pc = (role == 0) ? f.external_score_basepair : f.multibranch_score_basepair;
-      const float Qc = (role == 0) ? f.external_score_unpair : mun;
-      struct ABuf {
-        float xs[kUE];
-      };
-      uint32_t t = pingpong<ABuf, kUE, true>(
-          1u, d / kUE,
-          [&](ABuf& B, uint32_t t0) {
+    if (role != 2) {
+      const bool ext = role == 0 || role == 3;
+      const float Pc = ext ? f.external_score_basepair : f.multibranch_score_basepair;
+      const float Qc = ext ? f.external_score_unpair : mun;
+      float* __restrict__ slot = q.m[ext ? M_ZRE : M_ZRM] + od;
+      if (!AHEAD && zr_parked) {
+        // steps 1 .. d-1 were folded beside the previous diagonal: the last one is left
+        zr = lse8(*slot, qa[od] + Pc + Qc * 0.f, P8);
+      } else {
+        const uint32_t last = AHEAD ? D - 1u : D;  // steps t = 1 .. last of the D-step fold
+        struct ABuf {
+          float xs[kUE];
+        };
+        uint32_t t = pingpong<ABuf, kUE, true>(
+            1u, last / kUE,
+            [&](ABuf& B, uint32_t t0) {
 #pragma unroll
-            for (int u = 0; u < kUE; u++) B.xs[u] = qa[tri_off(n, t0 + u) + i];
-          },
-          [&](const ABuf& B, uint32_t t0) {
+              for (int u = 0; u < kUE; u++) B.xs[u] = qa[tri_off(n, t0 + u) + i];
+            },
+            [&](const ABuf& B, uint32_t t0) {
 #pragma unroll
-            for (int u = 0; u < kUE; u++)
-              zr = lse8(zr, B.xs[u] + Pc + Qc * static_cast<float>(d - t0 - u), P8);
-          });
-      for (; t <= d; t++)
-        zr = lse8(zr, qa[tri_off(n, t) + i] + Pc + Qc * static_cast<float>(d - t), P8);
-      if (leader) q.m[role == 0 ? M_ZRE : M_ZRM][od] = zr;
+              for (int u = 0; u < kUE; u++)
+                zr = lse8(zr, B.xs[u] + Pc + Qc * static_cast<float>(D - t0 - u), P8);
+            });
+        for (; t <= last; t++)
+          zr = lse8(zr, qa[tri_off(n, t) + i] + Pc + Qc * static_cast<float>(D - t), P8);
+      }
+      if (leader) *slot = zr;  // (AHEAD: parked partial sum)
+      if (AHEAD) return;
     }
   }
   float acc;

@@ -668,8 +668,10 @@ def test_latency_forms_bit_exact(params, contra, short):
         ctx.set("lat_inside", 2)          # eight chains per wave, 8-lane speculative logsumexp
         ctx.set("lat_pairs", 1)
         ctx.set("lat_merge", 0)           # (2-loop blocks beside the chains on a second stream)
+        ctx.set("lat_zr_ahead", 0)        # (CONTRAfold: both folds of a cell in one launch)
         lat4, logz5 = ctx.bpp_batch(seqs, contra, short)
         ctx.set("lat_merge", 1)
+        ctx.set("lat_zr_ahead", 1)
         ctx.set("lat_inside", 3)          # both: wave per chain below 300 chains, else eight per wave
         ctx.set("lat_e_waves", 200)       # (and the three-lanes form above 200 waves)
         lat5, logz6 = ctx.bpp_batch(seqs, contra, short)
