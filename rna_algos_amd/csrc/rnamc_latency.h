@@ -25,6 +25,9 @@
 struct Piece8 {
   float c0, c1, c2, c3;  // cubic piece (threadIdx & 7)
   float tlo, thi;        // its interval [tlo, thi)
+  // the same interval on the bits of z (z >= +0: bit order is value order), piece 7's
+  // stretched to every finite z above its lower end:  (bits(z) - lo_bits) < width
+  uint32_t lo_bits, width;
 };
 
 __device__ __forceinline__ Piece8 load_piece8() {
@@ -36,6 +39,8 @@ __device__ __forceinline__ Piece8 load_piece8() {
   r.c3 = kLseCoef[p][3];
   r.tlo = p ? kLseBreaks[p - 1] : -1.f;  // z >= 0 always
   r.thi = kLseBreaks[p];
+  r.lo_bits = p ? __float_as_uint(kLseBreaks[p - 1]) : 0u;
+  r.width = (p == 7 ? 0x7F800000u : __float_as_uint(kLseBreaks[p])) - r.lo_bits;
   return r;
 }
 
@@ -306,7 +311,94 @@ __device__ __forceinline__ float lse8(float sum, float x, const Piece8& P) {
   return (z < 11.862479f) ? __uint_as_float(v) : alt;
 }
 
-constexpr int kUE = 16;  // fold steps per operand buffer (two buffers)
+// The same step when both operands are FINITE (so z is): the lane of piece 7 also serves
+// the identity piece — it adds lo to z itself instead of to its cubic when z >= 11.862479
+// (src/utils.rs:589-591) — and the OR over the group is the result: 18 instructions where
+// lse8 takes 22.
+__device__ __forceinline__ float lse8_fin(float sum, float x, const Piece8& P) {
+  const float hi = vmax(sum, x);
+  const float lo = vmin(sum, x);
+  const float z = hi - lo;
+  float r = ((P.c0 * z + P.c1) * z + P.c2) * z + P.c3;
+  r = (z >= 11.862479f) ? z : r;
+  r = lo + r;
+  const bool sel = (__float_as_uint(z) - P.lo_bits) < P.width;
+  uint32_t v = sel ? __float_as_uint(r) : 0u;
+  v = dpp_or<0xB1>(v);
+  v = dpp_or<0x4E>(v);
+  v = dpp_or<0x141>(v);
+  return __uint_as_float(v);
+}
+
+// The value lane 8g + U holds, in every lane of group g (two DPP moves: each quad spreads
+// its lane U & 3, then the quads that do not hold lane U take the other quad's through
+// row_half_mirror).
+template <int U>
+__device__ __forceinline__ float bcast8(float v) {
+  constexpr int q = U & 3;
+  const int a = __builtin_amdgcn_update_dpp(0, static_cast<int>(__float_as_uint(v)),
+                                            q | (q << 2) | (q << 4) | (q << 6), 0xF, 0xF, false);
+  const int b = __builtin_amdgcn_update_dpp(a, a, 0x141 /* row_half_mirror */, 0xF,
+                                            (U < 4) ? 0xA : 0x5, false);
+  return __uint_as_float(static_cast<uint32_t>(b));
+}
+
+// Steps t_first .. t_last of eight chains (one per group of eight lanes).  The terms are
+// formed LANE-PARALLEL — lane p of a group loads the operands of step t0 + p (load), four such
+// blocks per operand buffer, and turns them into the term (form) — and reach the group
+// through bcast8: per step two DPP moves instead of the loads, address arithmetic and term
+// arithmetic of every lane for itself.  A block of eight steps whose terms and running sums
+// are all finite takes lse8_fin.
+constexpr uint32_t kEB = 32;  // steps per operand buffer
+struct EOp {
+  float a, b;  // the (up to) two operands of a step, as loaded
+};
+template <class Load, class Form>
+__device__ __forceinline__ float chain_e(float acc, uint32_t t_first, uint32_t t_last, Load&& load,
+                                         Form&& form, const Piece8& P8) {
+  if (t_last < t_first) return acc;
+  const uint32_t p = threadIdx.x & 7u;
+  struct GBuf {
+    EOp o[4];
+  };
+  (void)pingpong<GBuf, kEB, true>(
+      t_first, (t_last - t_first + kEB) / kEB,
+      [&](GBuf& B, uint32_t t0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) B.o[k] = load(min(t0 + 8u * k + p, t_last));
+      },
+      [&](const GBuf& B, uint32_t t0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t tk = t0 + 8u * k;
+          if (tk > t_last) break;
+          const EOp o = {pin(B.o[k].a), pin(B.o[k].b)};
+          const float g = form(o, min(tk + p, t_last));
+          const uint32_t cnt = min(8u, t_last + 1u - tk);
+          const bool fin = __builtin_amdgcn_ballot_w64(g == kNegInf || acc == kNegInf) == 0ull;
+          if (cnt == 8u && fin) {
+            acc = lse8_fin(acc, bcast8<0>(g), P8);
+            acc = lse8_fin(acc, bcast8<1>(g), P8);
+            acc = lse8_fin(acc, bcast8<2>(g), P8);
+            acc = lse8_fin(acc, bcast8<3>(g), P8);
+            acc = lse8_fin(acc, bcast8<4>(g), P8);
+            acc = lse8_fin(acc, bcast8<5>(g), P8);
+            acc = lse8_fin(acc, bcast8<6>(g), P8);
+            acc = lse8_fin(acc, bcast8<7>(g), P8);
+          } else {
+            acc = lse8(acc, bcast8<0>(g), P8);
+            if (cnt > 1u) acc = lse8(acc, bcast8<1>(g), P8);
+            if (cnt > 2u) acc = lse8(acc, bcast8<2>(g), P8);
+            if (cnt > 3u) acc = lse8(acc, bcast8<3>(g), P8);
+            if (cnt > 4u) acc = lse8(acc, bcast8<4>(g), P8);
+            if (cnt > 5u) acc = lse8(acc, bcast8<5>(g), P8);
+            if (cnt > 6u) acc = lse8(acc, bcast8<6>(g), P8);
+            if (cnt > 7u) acc = lse8(acc, bcast8<7>(g), P8);
+          }
+        }
+      });
+  return acc;
+}
 
 // (ROLE is a template parameter: chosen per step at run time, the wave-uniform role conditions
 // became a handful of scalar branches in every fold step)
@@ -351,22 +443,9 @@ __device__ __forceinline__ void inside_chain_e(const DeviceBatch& b, const Seq& 
         zr = lse8(*slot, qa[od] + Pc + Qc * 0.f, P8);
       } else {
         const uint32_t last = AHEAD ? D - 1u : D;  // steps t = 1 .. last of the D-step fold
-        struct ABuf {
-          float xs[kUE];
-        };
-        uint32_t t = pingpong<ABuf, kUE, true>(
-            1u, last / kUE,
-            [&](ABuf& B, uint32_t t0) {
-#pragma unroll
-              for (int u = 0; u < kUE; u++) B.xs[u] = qa[tri_off(n, t0 + u) + i];
-            },
-            [&](const ABuf& B, uint32_t t0) {
-#pragma unroll
-              for (int u = 0; u < kUE; u++)
-                zr = lse8(zr, B.xs[u] + Pc + Qc * static_cast<float>(D - t0 - u), P8);
-            });
-        for (; t <= last; t++)
-          zr = lse8(zr, qa[tri_off(n, t) + i] + Pc + Qc * static_cast<float>(D - t), P8);
+        zr = chain_e(
+            zr, 1u, last, [&](uint32_t t) { return EOp{qa[tri_off(n, t) + i], 0.f}; },
+            [&](const EOp& o, uint32_t t) { return o.a + Pc + Qc * static_cast<float>(D - t); }, P8);
       }
       if (leader) *slot = zr;  // (AHEAD: parked partial sum)
       if (AHEAD) return;
@@ -383,32 +462,19 @@ __device__ __forceinline__ void inside_chain_e(const DeviceBatch& b, const Seq& 
   }
   const float* __restrict__ pa = (CONTRA && role != 0) ? zrm : zre;
   const float* __restrict__ pb = q.m[role == 0 ? M_Z : M_Q1D];
-  auto step = [&](float ra, float rb, uint32_t t) {
-    float term;
-    if (!CONTRA) {
-      term = (role == 0) ? ra + rb : (role == 1 ? ra + c : rb + (ra + c));
-    } else {
-      term = (role == 1) ? ra + mun * static_cast<float>(t) : rb + ra;
-    }
-    acc = lse8(acc, term, P8);
-  };
-  struct SBuf {
-    float ra[kUE], rb[kUE];
-  };
-  uint32_t t = pingpong<SBuf, kUE, true>(
-      1u, d >= 1 ? (d - 1) / kUE : 0u,
-      [&](SBuf& B, uint32_t t0) {
-#pragma unroll
-        for (int u = 0; u < kUE; u++) {
-          B.ra[u] = pa[tri_off(n, d - t0 - u) + t0 + u + i];
-          B.rb[u] = pb[tri_off(n, t0 + u - 1) + i];
-        }
-      },
-      [&](const SBuf& B, uint32_t t0) {
-#pragma unroll
-        for (int u = 0; u < kUE; u++) step(B.ra[u], B.rb[u], t0 + u);
-      });
-  for (; t < d; t++) step(pa[tri_off(n, d - t) + t + i], pb[tri_off(n, t - 1) + i], t);
+  if (d >= 2u) {
+    constexpr bool one = role == 1;  // (its terms have one operand)
+    acc = chain_e(
+        acc, 1u, d - 1u,
+        [&](uint32_t t) {
+          return EOp{pa[tri_off(n, d - t) + t + i], one ? 0.f : pb[tri_off(n, t - 1u) + i]};
+        },
+        [&](const EOp& o, uint32_t t) {
+          if (!CONTRA) return (role == 0) ? o.a + o.b : (role == 1 ? o.a + c : o.b + (o.a + c));
+          return (role == 1) ? o.a + mun * static_cast<float>(t) : o.b + o.a;
+        },
+        P8);
+  }
   if (leader) {
     if (role == 0) q.m[M_Z][od] = acc;
     if (role == 1) q.m[M_Q1D][od] = acc;  // parked: inside_combine_lat turns it into sums_1ormore

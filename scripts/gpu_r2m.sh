@@ -1,8 +1,5 @@
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "latency_forms or random_small or single_sequence or long_sequence" 2>&1 | tail -4
-for v in 0 1; do
-echo "== profile=2 lat_zr_ahead=$v"
-SETS=profile=2,lat_zr_ahead=$v timeout -k 10 300 python scripts/quick_timing.py n4096 n1024 2>&1 | grep -v amdgpu.ids | grep "contra=True"
-done
+echo "== profile=2"
+SETS=profile=2 timeout -k 10 300 python scripts/quick_timing.py n4096 n1024 multi8x2048 2>&1 | grep -v amdgpu.ids | grep rep
