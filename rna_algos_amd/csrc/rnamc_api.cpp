@@ -93,7 +93,7 @@ struct rnamc_ctx {
   // issue-bound and loses: profiles/r02_latency_forms.txt)
   int64_t lat_inside = 2;
   int64_t lat_inside_waves = 2048;
-  int64_t lat_e_waves = 2048;
+  int64_t lat_e_waves = 3072;
   // debug: probs_multibranch and the pair-probability chains as two launches (timing splits)
   int64_t lat_split = 0;
   // one launch per diagonal in a latency-form group (chains + 2-loop blocks), no second stream
