@@ -91,6 +91,27 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) {
   return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v)));
 }
 
+// One general fold step of a wave-uniform chain with FINITE operands (`sum` comes out of a
+// lane read, i.e. an SGPR): the identity piece is a scalar branch away; otherwise lane p
+// (mod 8) evaluates cubic piece p and a 3-step DPP OR over each group of 8 hands the result of
+// the lane whose interval holds z to every lane (all groups see the same operands) — no
+// ballot, no second lane read.
+__device__ __forceinline__ float lse_w(float sum, float x, const Piece8& P) {
+  float hi, lo;
+  asm("v_max_f32 %0, %1, %2" : "=v"(hi) : "s"(sum), "v"(x));
+  asm("v_min_f32 %0, %1, %2" : "=v"(lo) : "s"(sum), "v"(x));
+  const float z = hi - lo;  // finite, >= 0
+  if (__ballot(__float_as_uint(z) >= kLseThrBits) != 0ull) return lo + z;
+  float r = ((P.c0 * z + P.c1) * z + P.c2) * z + P.c3;
+  r = lo + r;
+  const bool sel = (__float_as_uint(z) - P.lo_bits) < P.width;
+  uint32_t v = sel ? __float_as_uint(r) : 0u;
+  v = dpp_or<0xB1>(v);
+  v = dpp_or<0x4E>(v);
+  v = dpp_or<0x141>(v);
+  return __uint_as_float(v);
+}
+
 // Terms classified AHEAD of the chain.  The terms of the next block of steps (at most 256)
 // are computed lane-parallel; a finite term t < far_limit(sum at block start, ...) is certain
 // to meet the identity piece when the chain reaches it, whatever the steps in between did:
@@ -154,27 +175,33 @@ __device__ __forceinline__ float fold_block(float sum, const float (&a)[NT], flo
     if (a[c] > kNegInf) mag = vmax(mag, __builtin_fabsf(a[c]));
   }
   if (total == 0u) return sum;
-  const float lim = far_limit(sum, mag);
   __builtin_amdgcn_wave_barrier();  // (the previous block's reads are done)
 #pragma unroll
   for (int c = 0; c < NT; c++) {
     if (a[c] > kNegInf) buf[pos++] = a[c];
   }
   __builtin_amdgcn_wave_barrier();
+  // -inf (+) x is x (lse_u returns hi): a chain that has not met a finite term yet takes the
+  // block's first one as it is, and every step from there on has FINITE operands
+  uint32_t first = 0;
+  if (uni(__float_as_uint(sum)) == 0xFF800000u) {
+    sum = buf[0];
+    first = 1u;
+  }
+  const float lim = far_limit(sum, mag);
   // A lone wave issues one instruction every ~6.7 cycles whatever its kind
   // (scripts/ubench/far_step.hip), so the chain is laid out for the fewest instructions per
   // step: the running sum WALKS across the lanes.  Step l happens in lane l, which takes the
   // sum from lane l-1 through the DPP operand of its subtraction (wave_ror:1; lane 0 reads
   // lane 63, where the block's incoming sum still stands) — a sure-far step is two VALU
   // instructions and no lane read.  The other lanes compute values nobody uses.  A general
-  // step fetches sum and term into SGPRs, runs lse_u as before and leaves its result in
-  // every lane.
+  // step fetches sum and term into SGPRs, runs lse_w and leaves its result in every lane.
   for (uint32_t w0 = 0; w0 < total; w0 += 64u) {
     const uint32_t cnt = min(64u, total - w0);
     const float t = buf[w0 + lane];  // (past `total`: stale, masked below)
     const unsigned long long far = __builtin_amdgcn_ballot_w64(lane < cnt && sure_far(t, lim));
     float s = sum;  // uniform here
-    uint32_t l = 0;
+    uint32_t l = w0 == 0u ? first : 0u;
     while (l < cnt) {
       // the run of sure-far steps from l on (bits past cnt are clear), in straight-line
       // pieces of 16, 8, 4, 2, 1 steps: ~2 instructions per step and a dozen per run
@@ -187,7 +214,7 @@ __device__ __forceinline__ float fold_block(float sum, const float (&a)[NT], flo
       if (r & 2u) s = far_steps<2>(s, t);
       if (r & 1u) s = far_steps<1>(s, t);
       if (l < cnt) {
-        s = lse_u(lane_val(s, (l + 63u) & 63u), lane_val(t, l), P8);
+        s = lse_w(lane_val(s, (l + 63u) & 63u), lane_val(t, l), P8);
         l++;
       }
     }
