@@ -632,13 +632,12 @@ __device__ __forceinline__ void outside_tail_lat(const DeviceBatch& b, const Seq
 }
 
 // ----------------------------------------------------------------------------
-// The 2-loop blocks of one listed cell per wave.  Lane b of the wave owns probe (a, b) of the
-// current row a: it loads that pair's operand(s) and scores the loop with the plain scorer of
-// rnamc_scoring.h (same expression trees as the table-driven one of rnamc_probes.h; this
-// is the scorer behind FoldScores) — 31 - a terms computed side by side — and the chain then
-// folds the row's PRESENT pairs in ascending b through a ballot, scalar bit scans and
-// v_readlane.  An absent pair is a map miss in the reference (no fold step at all).  The
-// next row's terms are computed before the current row is folded.
+// The 2-loop blocks of one listed cell per wave.  The probes (a, b) are taken in fold order
+// (a ascending, then b), 64 per batch; lane l loads the operand(s) of probe m0 + l and scores
+// the loop with the plain scorer of rnamc_scoring.h (same expression trees as the
+// table-driven one of rnamc_probes.h; this is the scorer behind FoldScores), and fold_block
+// folds the batch's PRESENT pairs in lane order.  An absent pair is a map miss in the reference
+// (no fold step at all).  The next batch's terms are computed before the current one is folded.
 template <bool CONTRA, int MODE>
 __device__ __forceinline__ void inside_pair_lat(const DeviceBatch& b, const Seq& q, uint32_t d,
                                                 uint32_t i, const Piece8& P8) {
@@ -657,18 +656,31 @@ __device__ __forceinline__ void inside_pair_lat(const DeviceBatch& b, const Seq&
     // enclosed pairs (k,l) = (i+1+a, j-1-bb), a ascending, bb ascending (l descending),
     // a + bb <= 30, l > k  <=>  a + bb <= d-3
     const uint32_t lim = min(static_cast<uint32_t>(RNAMC_MAX_2LOOP_LEN), d - 3);
-    auto row_term = [&](uint32_t a) {
+    // the (lim+1)(lim+2)/2 probes in fold order, 64 per batch: lane l scores probe m0 + l
+    // (a scorer call costs ~1.8 us of dependent table lookups however many lanes take part:
+    // 8 batches instead of 31 rows)
+    const uint32_t nprobe = (lim + 1u) * (lim + 2u) / 2u;
+    // (a, r) of this lane's probe, carried from batch to batch: row a holds len = lim + 1 - a
+    uint32_t pa = 0, plen = lim + 1u, pr = lane;
+    auto batch_term = [&](uint32_t m0) {
       float term = kNegInf;
-      if (a <= lim && lane <= lim - a) {
-        const uint32_t k = i + 1u + a, l = j - 1u - lane;
+      while (plen != 0u && pr >= plen) {
+        pr -= plen;
+        plen--;
+        pa++;
+      }
+      const uint32_t a = pa, r = pr;
+      pr += 64u;
+      if (m0 + lane < nprobe) {
+        const uint32_t k = i + 1u + a, l = j - 1u - r;
         const float x = qb[tri_off(n, l - k) + k];
         if (x > kNegInf) term = x + model.twoloop(s, i, j, k, l);
       }
       return term;
     };
-    float cur = row_term(0u);
-    for (uint32_t a = 0; a <= lim; a++) {
-      const float nxt = row_term(a + 1u);  // (all -inf past the last row)
+    float cur = batch_term(0u);
+    for (uint32_t m0 = 0; m0 < nprobe; m0 += 64u) {
+      const float nxt = batch_term(m0 + 64u);  // (all -inf past the last batch)
       const float t[1] = {pin(cur)};
       sum = fold_block<1>(sum, t, steps, P8);
       cur = nxt;
@@ -713,22 +725,58 @@ __device__ __forceinline__ void outside_head_lat(const DeviceBatch& b, const Seq
     // enclosing pairs (k,l) = (i-1-a, j+1+bb), a ascending (k descending), bb ascending,
     // a + bb <= 30, k >= 0, l <= n-1
     const uint32_t lim = min(static_cast<uint32_t>(RNAMC_MAX_2LOOP_LEN), n - 3 - d);
-    auto row_term = [&](uint32_t a) {
-      float term = kNegInf;
-      if (a <= lim && a < i && lane <= lim - a && j + 1u + lane <= n - 1u) {
-        const uint32_t k = i - 1u - a, l = j + 1u + lane;
-        const uint32_t x = tri_off(n, l - k) + k;
-        const float qkl = qb[x];
-        if (qkl > kNegInf) term = lp[x] + qb_ij - qkl + model.twoloop(s, k, l, i, j);
+    // Turner: 64 probes per batch (its scorer costs ~1.8 us of dependent table lookups per
+    // call however many lanes take part: 8 calls instead of 31).  CONTRAfold: row by row (its
+    // scorer is cheap, and the shorter blocks are classified against a fresher sum):
+    // measured either way, profiles/r02_latency_forms.txt
+    if (!CONTRA) {
+      // (64 probes per batch in fold order, as in inside_pair_lat)
+      const uint32_t nprobe = (lim + 1u) * (lim + 2u) / 2u;
+      uint32_t pa = 0, plen = lim + 1u, pr = lane;
+      auto batch_term = [&](uint32_t m0) {
+        float term = kNegInf;
+        while (plen != 0u && pr >= plen) {
+          pr -= plen;
+          plen--;
+          pa++;
+        }
+        const uint32_t a = pa, r = pr;
+        pr += 64u;
+        if (m0 + lane < nprobe) {
+          if (a < i && j + 1u + r <= n - 1u) {
+            const uint32_t k = i - 1u - a, l = j + 1u + r;
+            const uint32_t x = tri_off(n, l - k) + k;
+            const float qkl = qb[x];
+            if (qkl > kNegInf) term = lp[x] + qb_ij - qkl + model.twoloop(s, k, l, i, j);
+          }
+        }
+        return term;
+      };
+      float cur = batch_term(0u);
+      for (uint32_t m0 = 0; m0 < nprobe; m0 += 64u) {
+        const float nxt = batch_term(m0 + 64u);
+        const float t[1] = {pin(cur)};
+        p = fold_block<1>(p, t, steps, P8);
+        cur = nxt;
       }
-      return term;
-    };
-    float cur = row_term(0u);
-    for (uint32_t a = 0; a <= lim; a++) {
-      const float nxt = row_term(a + 1u);
-      const float t[1] = {pin(cur)};
-      p = fold_block<1>(p, t, steps, P8);
-      cur = nxt;
+    } else {
+      auto row_term = [&](uint32_t a) {
+        float term = kNegInf;
+        if (a <= lim && a < i && lane <= lim - a && j + 1u + lane <= n - 1u) {
+          const uint32_t k = i - 1u - a, l = j + 1u + lane;
+          const uint32_t x = tri_off(n, l - k) + k;
+          const float qkl = qb[x];
+          if (qkl > kNegInf) term = lp[x] + qb_ij - qkl + model.twoloop(s, k, l, i, j);
+        }
+        return term;
+      };
+      float cur = row_term(0u);
+      for (uint32_t a = 0; a <= lim; a++) {
+        const float nxt = row_term(a + 1u);
+        const float t[1] = {pin(cur)};
+        p = fold_block<1>(p, t, steps, P8);
+        cur = nxt;
+      }
     }
   }
   if (lane == 0u) q.m[M_P][od] = p;
