@@ -590,9 +590,15 @@ def main():
                 ("k_outside<.,1> (probs_multibranch, one launch per anti-diagonal)" if split_head else
                  "k_outside<.,5> (probs_multibranch + 2-loop half of the pair probabilities, one "
                  "launch per anti-diagonal)") if l_tail else
-                "k_outside<.,7> (outside sweep, all roles, one launch per anti-diagonal)",
+                ("k_outside<.,7> (outside sweep, all roles, one launch per anti-diagonal)"
+                 if args.workload == "batch10k" else
+                 "k_outside_lat (latency form of a lone sequence: pair-probability chains, "
+                 "probs_multibranch and the 2-loop halves of one anti-diagonal in one launch)"),
                 b_main, ms_main, l_main, "k_outside_main",
-                note="runs beside the pair-probability kernels (other streams): they share the chip"),
+                note=("runs beside the pair-probability kernels (other streams): they share the chip"
+                      if args.workload == "batch10k" else
+                      "bound by the length of the dependent fold chains (3(n-d) steps per "
+                      "anti-diagonal), not by bytes: DESIGN.md section 4, latency forms")),
             "roofline_tail": roof("k_outside<.,2> (multibranch half of the pair probabilities)",
                                   b_tail, ms_tail, l_tail, "k_outside_tail"),
             "roofline_outside_sweep": {
