@@ -4,21 +4,23 @@
 //
 // Such a group is bound by the LENGTH of the dependent fold chains the reference's summation
 // order dictates (src/mccaskill_algo.rs:344-374 / 468-512 inside: n^2/2 steps; 594-601 /
-// 701-714 outside: 3 n^2/2 steps), not by HBM or VALU throughput: > 95 % of the chip idles.
-// So a whole WAVE is spent on ONE chain (same operations on the chain's value, same order,
-// bit for bit; every lane holds the same running sum, control flow is scalar):
-//  * 89 % of the outside multibranch fold steps and 68 % of all others add a term more than
-//    11.862479 below the running sum, where logsumexp is `min + (max - min)`
-//    (src/utils.rs:589-591).  With one chain per wave that case is a scalar branch away and
-//    costs 6 vector instructions (a wave that carried 64 independent chains would find some
-//    lane outside it at every step).
-//  * otherwise lane p (mod 8) evaluates cubic piece p of ln_exp_1p (src/utils.rs:602-627)
-//    speculatively, coefficients in registers; the lane whose interval holds z keeps the
-//    result and an OR over each group of 8 lanes (3 DPP steps) hands it to every lane: no
-//    LDS table on the critical path (137 instead of 208 cycles per dependent step,
-//    profiles/r02_ubench_lse_latency.txt).
-//  * operands of the next 32-64 steps are in flight in registers (a step takes 45-140
-//    cycles, a round trip to L2 / HBM 2000-4000); every lane loads the same address.
+// 701-714 outside: 3 n^2/2 steps), not by HBM or VALU throughput: > 95 % of the chip idles,
+// and a lone wave issues one instruction every ~6.7 cycles whatever its kind
+// (scripts/ubench/far_step.hip).  Every form here is the same operations on the chain's
+// value in the same order, bit for bit, laid out for the fewest instructions per step:
+//  * outside chains and 2-loop rows, one wave per chain (fold_block): the terms of the next
+//    block are formed lane-parallel and classified AHEAD of the chain; a term certain to meet
+//    the identity piece of logsumexp (`min + (max - min)`, src/utils.rs:589-591: 96 % of the
+//    outside pair-probability steps) costs two VALU instructions, the running sum walking
+//    from lane to lane through a DPP operand; the others take lse_w — a scalar branch for the
+//    identity piece, else lane p (mod 8) evaluates cubic piece p of ln_exp_1p
+//    (src/utils.rs:602-627) and a DPP OR over each group of 8 lanes hands the selected
+//    result to every lane: no LDS table on the chain;
+//  * inside folds, eight chains per wave (chain_e): inside terms stay near the sum, so every
+//    step evaluates the cubic — lanes 8g..8g+7 hold one cell's chain, one piece per lane;
+//  * operands are loaded lane-distributed, blocks ahead of the chain (a step takes 6-90 ns,
+//    a round trip to L2 / HBM 1-2 us), and handed on through opaque moves so that the
+//    compiler waits for exactly the load it needs (counted vmcnt).
 #ifndef RNAMC_LATENCY_H
 #define RNAMC_LATENCY_H
 
@@ -119,10 +121,10 @@ __device__ __forceinline__ float lse_w(float sum, float x, const Piece8& P) {
 // returns more than z).  With M >= every |term| of the block and >= |sum| + 256 (the sum
 // gains at most ln 2 per step), z < 2 M, one step loses < 1.5 M 2^-23 and 256 steps
 // < M 2^-14.4: the margin kept in hand is 1 for M < 2^12, 4 below 2^16, 64 below 2^20, and
-// beyond that nothing is classified.  For such a step logsumexp IS lse_far: hi = sum,
+// beyond that nothing is classified.  For such a step logsumexp IS  t + (sum - t):  hi = sum,
 // lo = t, z = hi - lo >= 11.862479, result lo + z (src/utils.rs:589-591) — two dependent
-// instructions, no compare and no branch on the chain.  A term of -inf leaves the sum as it
-// is (lse_u returns hi) and is no step at all.
+// instructions (far_steps), no compare and no branch on the chain.  A term of -inf leaves the
+// sum as it is (lse_u returns hi) and is no step at all.
 // `mag`: this lane's largest finite |term| (0 if it has none).
 __device__ __forceinline__ float far_limit(float sum, float mag) {
   const float m = vmax(mag, __builtin_fabsf(sum) + 256.f);  // (sum = -inf: nothing classified)
@@ -133,10 +135,6 @@ __device__ __forceinline__ float far_limit(float sum, float mag) {
   return sum - (11.862479f + margin);
 }
 __device__ __forceinline__ bool sure_far(float t, float lim) { return t < lim && t > kNegInf; }
-__device__ __forceinline__ float lse_far(float sum, float t) {
-  const float z = sum - t;
-  return t + z;
-}
 
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {  // set bits of m below this lane
   return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),

@@ -1,8 +1,4 @@
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for w in multi128x256 multi64x1024 multi512x256 multi2048x256; do
-for v in 0 2; do
-W=$w bash scripts/gpu_r2g.sh latency_mode=$v
-done
-done
+CONTRA=0 GSIZES=64,128,256,512,1024,8192 SETS=profile=1 timeout -k 10 600 python scripts/quick_timing.py batch2000 2>&1 | grep -v amdgpu.ids | grep rep
