@@ -630,6 +630,65 @@ __device__ __forceinline__ void outside_tail_lat(const DeviceBatch& b, const Seq
 }
 
 // ----------------------------------------------------------------------------
+// Turner 2-loop score with every table lookup issued at once (get_2loop_score,
+// src/utils.rs:207-366; same expression tree per loop class as Turner::twoloop of
+// rnamc_scoring.h, which walks the classes through branches: lanes of one wave hold different
+// classes, so the branchy form pays the dependent global loads of every class in turn,
+// ~1.8 us per call).  The bases come from two 40-byte windows staged in LDS (Win2), the
+// class picks ONE primary table entry per lane (stack / 1x1 / 1x2 / 2x2 / the terminal
+// mismatch table of the class), the second mismatch entry and the initiation entry are
+// loaded beside it: one round trip per call.
+// (ci,cj) closes, (ak,al) is enclosed; x1,x2 = the two bases inside ci, y1,y2 inside cj;
+// m2,m3 = the bases outside al and ak; a, b = unpaired bases on the two sides.
+struct Win2 {
+  uint8_t left[40], right[40];
+};
+
+__device__ __forceinline__ float turner_twoloop_flat(const rnamc_turner_scores& t, uint32_t a,
+                                                     uint32_t b, int ci, int cj, int x1, int x2,
+                                                     int y1, int y2, int ak, int al, int m2, int m3) {
+  const bool bulge = (a == 0u) != (b == 0u);
+  const uint32_t len = a + b;
+  const bool stack = len == 0u, bulge1 = bulge && len == 1u, bulgeN = bulge && len > 1u;
+  const bool i11 = a == 1u && b == 1u, i12 = a == 1u && b == 2u, i21 = a == 2u && b == 1u,
+             i22 = a == 2u && b == 2u;
+  const bool generic = !(stack || bulge || i11 || i12 || i21 || i22);
+  // primary entry
+  const float* tmx = (a == 1u || b == 1u) ? &t.terminal_mismatch_scores_1xmany[0][0][0][0]
+                     : ((a == 2u && b == 3u) || (a == 3u && b == 2u))
+                         ? &t.terminal_mismatch_scores_2x3[0][0][0][0]
+                         : &t.terminal_mismatch_scores_interior[0][0][0][0];
+  const float* pa;
+  if (stack || bulge1) {
+    pa = &t.stack_scores[ci][cj][ak][al];
+  } else if (i11) {
+    pa = &t.interior_scores_1x1[ci][cj][x1][y1][ak][al];
+  } else if (i12) {
+    pa = &t.interior_scores_1x2[ci][cj][x1][y1][y2][ak][al];
+  } else if (i21) {
+    pa = &t.interior_scores_1x2[al][ak][y1][x2][x1][cj][ci];
+  } else if (i22) {
+    pa = &t.interior_scores_2x2[ci][cj][x1][y1][x2][y2][ak][al];
+  } else {
+    pa = tmx + ((ci * 4 + cj) * 4 + x1) * 4 + y1;  // (bulgeN: read, not used)
+  }
+  const float* pb = tmx + ((al * 4 + ak) * 4 + m2) * 4 + m3;
+  const float* pc = bulge ? &t.bulge_scores_init[len] : &t.interior_scores_init[len];
+  const float A = *pa, B = *pb, C = *pc;  // three independent loads
+  const float penc = augu(ci, cj) ? t.helix_augu_end_penalty : 0.f;
+  const float peni = augu(ak, al) ? t.helix_augu_end_penalty : 0.f;
+  if (generic) {
+    const uint32_t diff = a > b ? a - b : b - a;
+    const float nin = t.ninio_coeff * static_cast<float>(diff);
+    const float mm = A + B;
+    return C + (nin > t.ninio_max ? nin : t.ninio_max) + mm + penc + peni;
+  }
+  if (bulge1) return C + A;
+  if (bulgeN) return C + penc + peni;
+  return A;
+}
+
+// ----------------------------------------------------------------------------
 // The 2-loop blocks of one listed cell per wave.  The probes (a, b) are taken in fold order
 // (a ascending, then b), 64 per batch; lane l loads the operand(s) of probe m0 + l and scores
 // the loop with the plain scorer of rnamc_scoring.h (same expression trees as the
@@ -658,6 +717,15 @@ __device__ __forceinline__ void inside_pair_lat(const DeviceBatch& b, const Seq&
     // (a scorer call costs ~1.8 us of dependent table lookups however many lanes take part:
     // 8 batches instead of 31 rows)
     const uint32_t nprobe = (lim + 1u) * (lim + 2u) / 2u;
+    // Turner: the bases around i (rightwards) and j (leftwards), for turner_twoloop_flat
+    __shared__ Win2 win;
+    if (!CONTRA) {
+      if (lane < 40u) {
+        win.left[lane] = s[min(i + lane, n - 1u)];
+        win.right[lane] = s[j >= lane ? j - lane : 0u];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
     // (a, r) of this lane's probe, carried from batch to batch: row a holds len = lim + 1 - a
     uint32_t pa = 0, plen = lim + 1u, pr = lane;
     auto batch_term = [&](uint32_t m0) {
@@ -672,7 +740,15 @@ __device__ __forceinline__ void inside_pair_lat(const DeviceBatch& b, const Seq&
       if (m0 + lane < nprobe) {
         const uint32_t k = i + 1u + a, l = j - 1u - r;
         const float x = qb[tri_off(n, l - k) + k];
-        if (x > kNegInf) term = x + model.twoloop(s, i, j, k, l);
+        float sc;
+        if (!CONTRA) {
+          sc = turner_twoloop_flat(b.params->turner, a, r, win.left[0], win.right[0], win.left[1],
+                                   win.left[2], win.right[1], win.right[2], win.left[1u + a],
+                                   win.right[1u + r], win.right[r], win.left[a]);
+        } else {
+          sc = model.twoloop(s, i, j, k, l);
+        }
+        if (x > kNegInf) term = x + sc;
       }
       return term;
     };
@@ -728,7 +804,14 @@ __device__ __forceinline__ void outside_head_lat(const DeviceBatch& b, const Seq
     // scorer is cheap, and the shorter blocks are classified against a fresher sum):
     // measured either way, profiles/r02_latency_forms.txt
     if (!CONTRA) {
-      // (64 probes per batch in fold order, as in inside_pair_lat)
+      // (64 probes per batch in fold order, as in inside_pair_lat; the bases around i
+      // (leftwards) and j (rightwards) for turner_twoloop_flat)
+      __shared__ Win2 win;
+      if (lane < 40u) {
+        win.left[lane] = s[i >= lane ? i - lane : 0u];
+        win.right[lane] = s[min(j + lane, n - 1u)];
+      }
+      __builtin_amdgcn_wave_barrier();
       const uint32_t nprobe = (lim + 1u) * (lim + 2u) / 2u;
       uint32_t pa = 0, plen = lim + 1u, pr = lane;
       auto batch_term = [&](uint32_t m0) {
@@ -745,7 +828,12 @@ __device__ __forceinline__ void outside_head_lat(const DeviceBatch& b, const Seq
             const uint32_t k = i - 1u - a, l = j + 1u + r;
             const uint32_t x = tri_off(n, l - k) + k;
             const float qkl = qb[x];
-            if (qkl > kNegInf) term = lp[x] + qb_ij - qkl + model.twoloop(s, k, l, i, j);
+            // (k,l) closes, (i,j) is enclosed
+            const float sc = turner_twoloop_flat(
+                b.params->turner, a, r, win.left[1u + a], win.right[1u + r], win.left[a],
+                win.left[a >= 1u ? a - 1u : 0u], win.right[r], win.right[r >= 1u ? r - 1u : 0u],
+                win.left[0], win.right[0], win.right[1], win.left[1]);
+            if (qkl > kNegInf) term = lp[x] + qb_ij - qkl + sc;
           }
         }
         return term;
