@@ -1,6 +1,6 @@
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "latency_forms or random_small or single_sequence or long_sequence" 2>&1 | tail -4
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "latency_forms or random_small or single_sequence or long_sequence or trna" 2>&1 | tail -4
 echo "== profile=2"
-SETS=profile=2 timeout -k 10 300 python scripts/quick_timing.py n4096 n1024 2>&1 | grep -v amdgpu.ids | grep rep
+SETS=profile=2 timeout -k 10 300 python scripts/quick_timing.py n1024 multi64x256 multi6x76 2>&1 | grep -v amdgpu.ids | grep rep1
