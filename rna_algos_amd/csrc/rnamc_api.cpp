@@ -82,9 +82,10 @@ struct rnamc_ctx {
   // positions a workgroup's window may span (sets its LDS footprint)
   int64_t head_lds = 0;
   // latency forms (rnamc_latency.h) for groups that cannot fill the chip: 0 never, 1 when the
-  // group's longest diagonal holds at most lat_max_cells cells over all its sequences, 2 always
+  // group's longest diagonal holds at most lat_max_cells cells over all its sequences (half of
+  // that under CONTRAfold), 2 always
   int64_t latency_mode = 1;
-  int64_t lat_max_cells = 16384;
+  int64_t lat_max_cells = 32768;
   // inside folds of such a group (lat_inside is a bit set, 0 = the three-lanes-per-cell form
   // throughout): bit 0 one wave per chain (terms classified ahead of the chain, as in the
   // outside forms) on the diagonals whose launches hold at most lat_inside_waves chains (3 per
@@ -373,9 +374,12 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
     // Latency-form group: folds(d) on `st` (k_inside_lat) beside the pair block of d+1 on
     // aux_stream; folds(d) need the pair block of d (aux, step before), the pair block of
     // d+1 needs the folds of d-1 (st, step before).
+    // (CONTRAfold's chains hold more general steps: its crossover against the batch forms lies
+    // at half the cells, profiles/r02_latency_forms.txt)
     const bool lat = c->latency_mode == 2 ||
                      (c->latency_mode == 1 &&
-                      static_cast<uint64_t>(nseq) * gmax <= static_cast<uint64_t>(c->lat_max_cells));
+                      static_cast<uint64_t>(nseq) * gmax <=
+                          static_cast<uint64_t>(contra ? c->lat_max_cells / 2 : c->lat_max_cells));
     const bool lat_in = lat && (c->lat_inside != 0 || c->lat_pairs != 0);
     if (lat_in) {
       bool have_a = false, have_b = false, combine_due = false, zr_parked = false;
