@@ -1,8 +1,6 @@
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for w in multi128x256 multi256x256 multi64x512 multi32x1024; do
-for v in 0 2; do
-W=$w bash scripts/gpu_r2g.sh latency_mode=$v
-done
-done
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "random_small or two_diagonal or trna or bench_scale" 2>&1 | tail -4
+echo "== top512"
+SETS=profile=1 timeout -k 10 300 python scripts/quick_timing.py top512 2>&1 | grep -v amdgpu.ids | grep rep
