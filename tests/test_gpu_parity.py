@@ -729,3 +729,24 @@ def test_latency_forms_large_magnitudes(scale, contra):
             assert np.float32(logz[0]).view(np.uint32) == np.float32(ref_logz[0]).view(np.uint32)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("contra", [False, True])
+def test_mid_size_group_default_knobs(params, contra):
+    """A ragged group of 40 sequences whose longest diagonal holds 28 000 cells, at default
+    knobs: above CONTRAfold's latency-form limit (16 384 cells: batch forms) and below Turner's
+    (32 768: latency forms, one launch per diagonal)."""
+    from rna_algos_amd.mccaskill_algo import Context
+    rng = np.random.default_rng(4040)
+    lens = np.concatenate([[700], rng.integers(150, 700, 39)])
+    seqs = [rng.integers(0, 4, int(n)).astype(np.uint8) for n in lens]
+    ctx = Context(params, device=0)
+    try:
+        got, logz = ctx.bpp_batch(seqs, contra, False)
+        assert ctx.stats()["n_groups"] == 1
+    finally:
+        ctx.close()
+    ref, ref_logz = O.bpp_batch(params.ptr, seqs, contra, False, n_threads=16)
+    for s, g, r in zip(seqs, got, ref):
+        assert_same(g.packed, r, f"n={len(s)}")
+    assert np.array_equal(np.asarray(logz).view(np.uint32), np.asarray(ref_logz).view(np.uint32))
