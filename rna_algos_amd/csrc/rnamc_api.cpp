@@ -94,7 +94,7 @@ struct rnamc_ctx {
   // issue-bound and loses: profiles/r02_latency_forms.txt)
   int64_t lat_inside = 2;
   int64_t lat_inside_waves = 2048;
-  int64_t lat_e_waves = 3072;
+  int64_t lat_e_waves = 2048;
   // debug: probs_multibranch and the pair-probability chains as two launches (timing splits)
   int64_t lat_split = 0;
   // one launch per diagonal in a latency-form group (chains + 2-loop blocks), no second stream
@@ -394,11 +394,14 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
         const uint64_t chains = 3ull * (gmax - d) * active(d);
         // (CONTRAfold, eight-chains form: two more chain kinds per cell, see lat_zr_ahead)
         const uint64_t kinds_e = (contra && c->lat_zr_ahead != 0) ? 5 : 3;
+        // (CONTRAfold: three times the waves — its three-lanes form folds two chains per cell
+        // one after the other, measured crossover in profiles/r02_latency_forms.txt)
+        const uint64_t e_waves = static_cast<uint64_t>(c->lat_e_waves) * (contra ? 3 : 1);
         // lat_inside bit 0: one wave per chain on the diagonals with few chains; bit 1: eight
         // chains per wave on the diagonals with few enough waves
         const int form = !do_sums ? 0
                          : ((c->lat_inside & 1) && chains <= static_cast<uint64_t>(c->lat_inside_waves)) ? 1
-                         : ((c->lat_inside & 2) && (chains / 3 * kinds_e + 7) / 8 <= static_cast<uint64_t>(c->lat_e_waves)) ? 2 : 0;
+                         : ((c->lat_inside & 2) && (chains / 3 * kinds_e + 7) / 8 <= e_waves) ? 2 : 0;
         const bool wave_form = form != 0;
         // CONTRAfold: a cell's sums_rightmost_basepairs folds (d steps) precede its other
         // folds (d steps more); all but their last step needs nothing of diagonal d, so the

@@ -1,4 +1,8 @@
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "mid_size_group" 2>&1 | tail -3
+for w in multi8x2048 multi16x1024; do
+for v in 2048 3072 4096 6144; do
+W=$w bash scripts/gpu_r2g.sh lat_e_waves=$v
+done
+done
