@@ -25,23 +25,23 @@
 typedef struct {
   uint32_t n;
   /* FoldSums, mccaskill_algo.rs:3-11, init at 213-226 */
-  float* sums_external;                        /* 0.0 everywhere        */
-  float* sums_rightmost_basepairs_external;    /* -inf                  */
-  float* sums_rightmost_basepairs_multibranch; /* -inf                  */
-  float* sums_close;                           /* sparse -> -inf        */
-  float* sums_accessible;                      /* sparse -> -inf        */
-  float* sums_multibranch;                     /* -inf                  */
-  float* sums_1ormore_basepairs;               /* -inf                  */
+  Score* sums_external;                        /* 0.0 everywhere        */
+  Score* sums_rightmost_basepairs_external;    /* -inf                  */
+  Score* sums_rightmost_basepairs_multibranch; /* -inf                  */
+  Score* sums_close;                           /* sparse -> -inf        */
+  Score* sums_accessible;                      /* sparse -> -inf        */
+  Score* sums_multibranch;                     /* -inf                  */
+  Score* sums_1ormore_basepairs;               /* -inf                  */
   /* FoldScores (dense), mccaskill_algo.rs:13-19 */
-  float* multibranch_close_scores;
+  Score* multibranch_close_scores;
   /* outside, mccaskill_algo.rs:527-529 */
-  float* basepair_probs; /* log domain until the final expf map; -inf = absent */
-  float* probs_multibranch;
-  float* probs_multibranch2;
+  Score* basepair_probs; /* log domain until the final expf map; -inf = absent */
+  Score* probs_multibranch;
+  Score* probs_multibranch2;
   /* optional recorder of the remaining FoldScores maps (rnamc_oracle_fold_scores):
    * dense n x n with NaN = key absent, and the list of twoloop_scores inserts */
-  float* rec_hairpin;
-  float* rec_accessible;
+  Score* rec_hairpin;
+  Score* rec_accessible;
   rnamc_twoloop_score* rec_twoloop;
   size_t rec_count, rec_cap;
   int rec_failed;
@@ -63,8 +63,8 @@ static void rec_twoloop(ostate* s, uint32_t i, uint32_t j, uint32_t k, uint32_t 
   s->rec_twoloop[s->rec_count++] = e;
 }
 
-static float* alloc_fill(size_t count, float v) {
-  float* p = (float*)malloc(count * sizeof(float));
+static Score* alloc_fill(size_t count, Score v) {
+  Score* p = (Score*)malloc(count * sizeof(Score));
   if (!p) return NULL;
   for (size_t x = 0; x < count; x++) p[x] = v;
   return p;
@@ -380,6 +380,7 @@ static int check_args(const rnamc_params* p, const uint8_t* seq, uint32_t n) {
   return RNAMC_OK;
 }
 
+#ifndef ORACLE_EXACT /* the exported entry points of the reference restatement */
 /* mccaskill_algo — mccaskill_algo.rs:247-280.  `mats`, if non-NULL, receives
  * copies of DP matrices (each n*n row-major, caller-allocated, entries may be
  * NULL) in the order of rnamc_debug_fetch's `which`. */
@@ -414,7 +415,7 @@ int rnamc_oracle_bpp_dump(const rnamc_params* p, const uint8_t* seq, uint32_t n,
       }
   }
   if (mats) {
-    const float* src[7] = {s.sums_close,
+    const Score* src[7] = {s.sums_close,
                            s.sums_accessible,
                            s.sums_external,
                            s.sums_1ormore_basepairs,
@@ -422,7 +423,8 @@ int rnamc_oracle_bpp_dump(const rnamc_params* p, const uint8_t* seq, uint32_t n,
                            s.probs_multibranch,
                            s.probs_multibranch2};
     for (int m = 0; m < 7; m++)
-      if (mats[m]) memcpy(mats[m], src[m], (size_t)n * n * sizeof(float));
+      if (mats[m])
+        for (size_t x = 0; x < (size_t)n * n; x++) mats[m][x] = (float)src[m][x];
   }
   ostate_free(&s);
   return RNAMC_OK;
@@ -556,7 +558,7 @@ int rnamc_oracle_centroid_fold(const float* bpp_packed, uint32_t n, float centro
                                uint32_t* pairs_out, uint32_t max_pairs, uint32_t* n_pairs,
                                float* expect_accuracy) {
   if (!bpp_packed || n == 0 || !n_pairs) return RNAMC_ERR_INVALID_ARG;
-  float* m = alloc_fill((size_t)n * n, 0.f);
+  float* m = (float*)calloc((size_t)n * n, sizeof(float));
   if (!m) return RNAMC_ERR_OOM;
 #define BPP(i, j) bpp_packed[(size_t)((j) - (i)) * n - (size_t)((j) - (i)) * ((j) - (i)-1) / 2 + (i)]
   for (uint32_t subseq_len = 1; subseq_len <= n; subseq_len++) {
@@ -625,3 +627,4 @@ int rnamc_oracle_centroid_fold(const float* bpp_packed, uint32_t n, float centro
   free(m);
   return RNAMC_OK;
 }
+#endif /* !ORACLE_EXACT */

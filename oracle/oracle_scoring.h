@@ -26,7 +26,15 @@
 
 #include "../include/rnamc.h"
 
+#ifdef ORACLE_EXACT
+/* NOT the reference's arithmetic: the same recurrences and loop scores evaluated in f64
+ * with an exact logsumexp / exp (mccaskill_exact.c).  It checks the tree-order summation
+ * mode of the HIP path (rnamc_ctx_set "summation_mode" 1), which cannot be bit-compared
+ * with the reference's order-dependent fold. */
+typedef double Score;
+#else
 typedef float Score;
+#endif
 #define ONEG_INF (-INFINITY)
 
 /* src/utils.rs:162-164 — AU | CG | GC | GU | UA | UG with A,C,G,U = 0,1,2,3. */
@@ -73,14 +81,22 @@ static inline void o_logsumexp(Score* sum, Score x) {
   if (!isfinite(*sum)) {
     *sum = x;
   } else {
+#ifdef ORACLE_EXACT
+    Score hi = *sum > x ? *sum : x, lo = *sum > x ? x : *sum;
+    *sum = hi + log1p(exp(lo - hi));
+#else
     Score y = fminf(*sum, x);
     Score z = fmaxf(*sum, x) - y;
     *sum = y + (z >= 11.862479f ? z : o_ln_exp_1p(z));
+#endif
   }
 }
 
 /* src/utils.rs:630-655 */
 static inline Score o_expf(Score x) {
+#ifdef ORACLE_EXACT
+  return exp(x);
+#else
   if (x < -2.4915035f) {
     if (x < -5.8622823f) {
       if (x < -9.91152f) {
@@ -104,6 +120,7 @@ static inline Score o_expf(Score x) {
   } else {
     return expf(x);
   }
+#endif
 }
 
 /* ------------------------- Turner model, src/utils.rs:166-411 ------------- */

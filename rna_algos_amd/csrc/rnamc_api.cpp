@@ -46,6 +46,9 @@ struct rnamc_ctx {
   uint64_t ws_floats = 0;
   SeqDesc* d_seqs = nullptr;
   uint64_t seqs_cap = 0;
+  TreeSeq* d_tseqs = nullptr;  // descriptors of the tree-order mode
+  uint64_t tseqs_cap = 0;
+  std::vector<TreeSeq> h_tseqs;  // (host copy: source of an async upload, must outlive it)
   // host-buffer entry: device staging of bases / result / log partition (grow-only)
   // The result is staged per lock-step GROUP in two alternating device buffers: group g's
   // D2H (copy stream, pinned bounce chunks, a host thread) runs while group g+1 sweeps.
@@ -64,6 +67,9 @@ struct rnamc_ctx {
   std::vector<hipEvent_t> ev_a, ev_b, ev_c;   // per-diagonal completion, ring of 16
   std::recursive_mutex mu;  // rnamc_fold_scores re-enters rnamc_bpp_batch
   // knobs
+  // 0: every logsumexp fold in the reference's order (the parity gate); 1: order-free sums
+  // (rnamc_tree.hip), not bit-comparable with the reference
+  int64_t summation_mode = 0;
   int64_t group_max_seqs = 8192;
   int64_t group_max_nt = 2ll << 20;  // a group holds ~2M nucleotides (or 64 GB of DP state)
   int64_t group_ws_bytes = 64ll << 30;
@@ -704,6 +710,185 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
   return RNAMC_OK;
 }
 
+// Tree-order summation mode (rnamc_tree.hip): same grouping and per-diagonal sweep, dense
+// n x n matrices, one workgroup per cell.  Fills c->descs / group_* like run_batch so that the
+// host-buffer entry's drain thread works unchanged.
+int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint64_t* offsets,
+                   bool contra, bool allows_short, float* d_out, const uint64_t* out_offsets,
+                   float* d_logz, hipStream_t st, const GroupHooks* hooks = nullptr) {
+  c->stats = rnamc_batch_stats{};
+  c->kev_class.clear();
+  c->descs.clear();
+  c->group_begin.clear();
+  c->group_out_floats.clear();
+  if (n_seqs == 0) return RNAMC_OK;
+  uint32_t max_n = 0;
+  for (uint32_t s = 0; s < n_seqs; s++) {
+    if (offsets[s + 1] < offsets[s]) return RNAMC_ERR_INVALID_ARG;
+    const uint64_t n = offsets[s + 1] - offsets[s];
+    if (n == 0) return RNAMC_ERR_EMPTY_SEQ;
+    if (n > RNAMC_MAX_SEQ_LEN) return RNAMC_ERR_SEQ_TOO_LONG;
+    max_n = std::max<uint32_t>(max_n, static_cast<uint32_t>(n));
+  }
+  int rc = ensure_hp_init(c, max_n);
+  if (rc) return rc;
+  std::vector<uint32_t> order(n_seqs);
+  std::iota(order.begin(), order.end(), 0u);
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    return (offsets[a + 1] - offsets[a]) > (offsets[b + 1] - offsets[b]);
+  });
+  const uint64_t ws_cap_floats = static_cast<uint64_t>(std::max<int64_t>(c->group_ws_bytes, 1)) / 4;
+  std::vector<TreeSeq>& tseqs = c->h_tseqs;
+  tseqs.clear();
+  tseqs.reserve(n_seqs);
+  uint64_t max_group_floats = 0;
+  {
+    uint64_t cur = 0, cur_nt = 0, cur_out = 0;
+    uint32_t cnt = 0;
+    for (uint32_t x = 0; x < n_seqs; x++) {
+      const uint32_t s = order[x];
+      const uint32_t n = static_cast<uint32_t>(offsets[s + 1] - offsets[s]);
+      TreeSeq ts{};
+      ts.n = n;
+      ts.ld = ((n + 31u) & ~31u) + 32u;
+      ts.msz = ((static_cast<uint64_t>(ts.ld) * n + 63ull) & ~63ull) + 64ull;
+      const uint64_t need = ts.msz * T_COUNT + 2ull * ((static_cast<uint64_t>(n) + 64ull + 63ull) & ~63ull);
+      if (cnt > 0 && (cnt >= static_cast<uint32_t>(c->group_max_seqs) ||
+                      cur_nt + n > static_cast<uint64_t>(c->group_max_nt) ||
+                      cur + need > ws_cap_floats)) {
+        max_group_floats = std::max(max_group_floats, cur);
+        c->group_out_floats.push_back(cur_out);
+        cur = cur_nt = cur_out = 0;
+        cnt = 0;
+      }
+      if (cnt == 0) c->group_begin.push_back(static_cast<uint32_t>(c->descs.size()));
+      ts.seq_off = offsets[s];
+      ts.ws_off = cur;
+      ts.out_off = hooks ? cur_out : out_offsets[s];
+      ts.batch_idx = s;
+      tseqs.push_back(ts);
+      SeqDesc sd{};  // host bookkeeping shared with the reference-order path
+      sd.n = n;
+      sd.seq_off = ts.seq_off;
+      sd.ws_off = ts.ws_off;
+      sd.out_off = ts.out_off;
+      sd.batch_idx = s;
+      c->descs.push_back(sd);
+      cur += need;
+      cur_nt += n;
+      cur_out += rnamc_bpp_len(n);
+      cnt++;
+    }
+    max_group_floats = std::max(max_group_floats, cur);
+    c->group_out_floats.push_back(cur_out);
+    c->group_begin.push_back(static_cast<uint32_t>(c->descs.size()));
+  }
+  rc = ensure_ws(c, max_group_floats);
+  if (rc) return rc;
+  if (c->tseqs_cap < tseqs.size()) {
+    if (c->d_tseqs) {
+      HIPCHK(hipDeviceSynchronize());
+      HIPCHK(hipFree(c->d_tseqs));
+      c->d_tseqs = nullptr;
+      c->tseqs_cap = 0;
+    }
+    const uint64_t cap = std::max<uint64_t>(tseqs.size(), 1024);
+    HIPCHK(hipMalloc(&c->d_tseqs, cap * sizeof(TreeSeq)));
+    c->tseqs_cap = cap;
+  }
+  HIPCHK(hipMemcpyAsync(c->d_tseqs, tseqs.data(), tseqs.size() * sizeof(TreeSeq),
+                        hipMemcpyHostToDevice, st));
+  const size_t n_groups = c->group_begin.size() - 1;
+  const bool prof = c->profile != 0;
+  if (prof) {
+    while (c->events.size() < n_groups * 4) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreate(&e));
+      c->events.push_back(e);
+    }
+  }
+  const uint32_t dmin_in = contra ? 0u : (RNAMC_MIN_SPAN_HAIRPIN_CLOSE - 1);
+  const uint32_t dmin_out = (contra && allows_short) ? 1u : (RNAMC_MIN_SPAN_HAIRPIN_CLOSE - 1);
+  for (size_t g = 0; g < n_groups; g++) {
+    const uint32_t gb = c->group_begin[g], ge = c->group_begin[g + 1];
+    const uint32_t nseq = ge - gb;
+    const uint32_t gmax = c->descs[gb].n;
+    TreeBatch b{};
+    b.seqs = c->d_tseqs + gb;
+    b.one = tseqs[gb];
+    b.use_one = nseq == 1 ? 1u : 0u;
+    b.bases = d_bases;
+    b.workspace = c->d_ws;
+    b.out = d_out;
+    if (hooks) {
+      rc = hooks->before(g, &b.out);
+      if (rc) return rc;
+    }
+    b.log_partition = d_logz;
+    b.params = c->d_params;
+    b.hp_init = c->d_hp_init;
+    b.allows_short_hairpins = allows_short ? 1 : 0;
+    auto active = [&](uint32_t d) {  // sequences with n > d form a prefix of the group
+      uint32_t lo = 0, hi = nseq;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (c->descs[gb + mid].n > d) lo = mid + 1; else hi = mid;
+      }
+      return lo;
+    };
+    if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 0], st));
+    launch_tree_init(b, nseq, gmax, contra, 0, st);
+    c->stats.launches_other++;
+    for (uint32_t d = dmin_in; d < gmax; d++) {
+      launch_tree_inside(b, contra, d, gmax, active(d), st);
+      c->stats.launches_inside++;
+    }
+    if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 1], st));
+    launch_tree_init(b, nseq, gmax, contra, 1, st);
+    c->stats.launches_other++;
+    for (uint32_t d = gmax; d-- > dmin_out;) {
+      launch_tree_outside(b, contra, d, gmax, active(d), st);
+      c->stats.launches_outside++;
+    }
+    if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 2], st));
+    launch_tree_finalize(b, nseq, gmax, st);
+    c->stats.launches_other++;
+    if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 3], st));
+    HIPCHK(hipGetLastError());
+    if (hooks) {
+      rc = hooks->after(g, gb, nseq);
+      if (rc) return rc;
+    }
+  }
+  c->stats.n_groups = n_groups;
+  c->stats.workspace_bytes = c->ws_floats * sizeof(float);
+  if (prof) {
+    HIPCHK(hipStreamSynchronize(st));
+    for (size_t g = 0; g < n_groups; g++) {
+      float a = 0, bms = 0, cc = 0;
+      HIPCHK(hipEventElapsedTime(&a, c->events[4 * g + 0], c->events[4 * g + 1]));
+      HIPCHK(hipEventElapsedTime(&bms, c->events[4 * g + 1], c->events[4 * g + 2]));
+      HIPCHK(hipEventElapsedTime(&cc, c->events[4 * g + 2], c->events[4 * g + 3]));
+      c->stats.ms_inside += a;
+      c->stats.ms_outside += bms;
+      c->stats.ms_other += cc;
+    }
+  }
+  return RNAMC_OK;
+}
+
+// the sweep of the context's summation mode (rnamc_fold_scores needs the reference-order
+// workspace layout and always takes that path)
+int run_batch_mode(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint64_t* offsets,
+                   bool contra, bool allows_short, float* d_out, const uint64_t* out_offsets,
+                   float* d_logz, hipStream_t st, const GroupHooks* hooks = nullptr) {
+  if (c->summation_mode == 1 && !c->inside_only)
+    return run_batch_tree(c, n_seqs, d_bases, offsets, contra, allows_short, d_out, out_offsets,
+                          d_logz, st, hooks);
+  return run_batch(c, n_seqs, d_bases, offsets, contra, allows_short, d_out, out_offsets, d_logz, st,
+                   hooks);
+}
+
 // FoldScores of one sequence on the host, given the sums_close key set (packed
 // diagonal-major, finite = key present).  Work is split by closing diagonal.
 template <class Model>
@@ -860,6 +1045,7 @@ void rnamc_ctx_destroy(rnamc_ctx* c) {
     if (c->d_hp_init) (void)hipFree(c->d_hp_init);
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_seqs) (void)hipFree(c->d_seqs);
+    if (c->d_tseqs) (void)hipFree(c->d_tseqs);
   }
   delete c;
 }
@@ -884,7 +1070,9 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
   if (!c || !name) return RNAMC_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lock(c->mu);
   const std::string k(name);
-  if (k == "group_max_seqs" && value >= 1) {
+  if (k == "summation_mode" && (value == 0 || value == 1)) {
+    c->summation_mode = value;
+  } else if (k == "group_max_seqs" && value >= 1) {
     c->group_max_seqs = std::min<int64_t>(value, 65535);
   } else if (k == "group_max_nt" && value >= 1) {
     c->group_max_nt = value;
@@ -951,8 +1139,9 @@ int rnamc_bpp_batch_device(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases
   std::lock_guard<std::recursive_mutex> lock(c->mu);
   DeviceGuard guard(c->device);
   if (!guard.ok) return RNAMC_ERR_NO_DEVICE;
-  return run_batch(c, n_seqs, d_bases, offsets, uses_contra_model != 0, allows_short_hairpins != 0,
-                   d_bpp, out_offsets, d_log_partition, static_cast<hipStream_t>(hip_stream));
+  return run_batch_mode(c, n_seqs, d_bases, offsets, uses_contra_model != 0,
+                        allows_short_hairpins != 0, d_bpp, out_offsets, d_log_partition,
+                        static_cast<hipStream_t>(hip_stream));
 }
 
 int rnamc_bpp_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* bases, const uint64_t* offsets,
@@ -1116,9 +1305,9 @@ int rnamc_bpp_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* bases, const u
     cv.notify_all();
     return RNAMC_OK;
   };
-  int rc = run_batch(c, n_seqs, c->st_bases, doff.data(), uses_contra_model != 0,
-                     allows_short_hairpins != 0, nullptr, out_offsets, c->st_logz, c->own_stream,
-                     &hooks);
+  int rc = run_batch_mode(c, n_seqs, c->st_bases, doff.data(), uses_contra_model != 0,
+                          allows_short_hairpins != 0, nullptr, out_offsets, c->st_logz,
+                          c->own_stream, &hooks);
   {
     std::lock_guard<std::mutex> lk(mu);
     stop = true;

@@ -81,6 +81,51 @@ void launch_durbin(const DurbinPair* d_pairs, uint32_t n_pairs, uint32_t max_cel
 void launch_finalize(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, uint32_t dmin_out,
                      hipStream_t st);
 
+// ---- tree-order summation mode (rnamc_tree.hip) ----
+// Dense n x n matrices with row stride ld (>= n + 32, a multiple of 32 floats), msz floats
+// each; "row" = [i * ld + j], "col" = [j * ld + i].  The outside sweep reuses four slots.
+enum TreeMat : int {
+  T_QB = 0,   // sums_close                                   row
+  T_QA = 1,   // sums_accessible                              row
+  T_Q1R = 2,  // sums_1ormore_basepairs                       row
+  T_Q1C = 3,  // sums_1ormore_basepairs                       col
+  T_ZRE = 4,  // sums_rightmost_basepairs_external            col | outside: W = (P + mbclose) - Qb, row
+  T_ZRM = 5,  // sums_rightmost_basepairs_multibranch         col | outside: R = Pm (+) Pm2, col
+  T_QM = 6,   // sums_multibranch                             row | outside: probs_multibranch2, row
+  T_U = 7,    // column prefix of Zr_mb (first fold of L_c)   col | outside: column prefix of Pm, col
+  T_COUNT = 8
+};
+struct TreeSeq {
+  uint32_t n, ld;
+  uint64_t msz;       // floats per matrix
+  uint64_t seq_off;   // first base in the bases buffer
+  uint64_t ws_off;    // float offset of the first matrix; after the T_COUNT matrices come the
+                      // vectors Z(0,.) and Z(.,n-1), n + 64 floats each
+  uint64_t out_off;   // float offset of the packed bpp triangle in the output
+  uint32_t batch_idx;
+  uint32_t pad_;
+};
+struct TreeBatch {
+  const TreeSeq* seqs;  // descriptors of the group (device memory)
+  TreeSeq one;          // the descriptor itself when the group is a single sequence (use_one):
+  uint32_t use_one;     // saves the dependent descriptor load in front of every launch
+  const uint8_t* bases;
+  float* workspace;
+  float* out;
+  float* log_partition;
+  const rnamc_params* params;
+  const float* hp_init;
+  int allows_short_hairpins;
+};
+// what = 0: everything before the inside sweep; 1: the four reused slots before the outside sweep
+void launch_tree_init(const TreeBatch& b, uint32_t nseq, uint32_t max_n, bool contra, int what,
+                      hipStream_t st);
+void launch_tree_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
+                        hipStream_t st);
+void launch_tree_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
+                         hipStream_t st);
+void launch_tree_finalize(const TreeBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st);
+
 }  // namespace rnamc
 
 #endif

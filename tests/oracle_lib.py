@@ -27,6 +27,7 @@ def lib():
         L.rnamc_oracle_bpp_dump.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, vp, vp, vp]
         L.rnamc_oracle_bpp_batch.argtypes = [vp, C.c_uint32, vp, vp, C.c_int, C.c_int, vp, vp, vp,
                                              C.c_uint32]
+        L.rnamc_oracle_exact_bpp.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, vp, vp]
         L.rnamc_oracle_bruteforce.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, vp, vp, vp]
         L.rnamc_oracle_fold_scores.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, vp, vp, vp,
                                                C.POINTER(vp), C.POINTER(C.c_uint64)]
@@ -52,6 +53,18 @@ def bpp(params_ptr, seq, contra, short=False):
     _chk(lib().rnamc_oracle_bpp(params_ptr, seq.ctypes.data, n, int(contra), int(short),
                                 out.ctypes.data, logz.ctypes.data))
     return out, np.float32(logz[0])
+
+
+def exact_bpp(params_ptr, seq, contra, short=False):
+    """The same recurrences in f64 with an exact logsumexp (oracle/mccaskill_exact.c; NOT the
+    reference's arithmetic) -> (packed bpp f64[n(n+1)/2], ln Z f64)"""
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    n = seq.shape[0]
+    out = np.empty(n * (n + 1) // 2, dtype=np.float64)
+    logz = np.zeros(1, dtype=np.float64)
+    _chk(lib().rnamc_oracle_exact_bpp(params_ptr, seq.ctypes.data, n, int(contra), int(short),
+                                      out.ctypes.data, logz.ctypes.data))
+    return out, float(logz[0])
 
 
 def bpp_dump(params_ptr, seq, contra, short=False):
