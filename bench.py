@@ -59,6 +59,10 @@ def shard_banded(costs, world):
     order = np.argsort(-np.asarray(costs, dtype=np.float64), kind="stable")
     csum = np.cumsum(np.asarray(costs, dtype=np.float64)[order])
     cuts = np.searchsorted(csum, csum[-1] * np.arange(1, world) / world)
+    if len(order) >= world:  # no empty band while there are units to give (rnamc_shard_plan)
+        for k in range(world - 1):
+            lo = (cuts[k - 1] if k else 0) + 1
+            cuts[k] = min(max(cuts[k], lo), len(order) - (world - 1 - k))
     return [np.array(x, dtype=np.int64) for x in np.split(order, cuts)]
 
 

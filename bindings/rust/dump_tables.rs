@@ -25,7 +25,7 @@ use rna_algos::mccaskill_algo::*;
 use rna_algos::utils::*;
 use std::io::Write;
 
-const RNAMC_ABI_VERSION: u32 = 2;
+const RNAMC_ABI_VERSION: u32 = 3;
 const MAX_SPECIAL: usize = 64; // RNAMC_MAX_SPECIAL_HAIRPINS
 const SPECIAL_W: usize = 16; // RNAMC_MAX_SPECIAL_HAIRPIN_LEN
 

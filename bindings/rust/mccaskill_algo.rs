@@ -31,6 +31,11 @@ pub struct RnamcCtx {
 }
 
 #[repr(C)]
+pub struct RnamcPool {
+  _private: [u8; 0],
+}
+
+#[repr(C)]
 #[derive(Clone, Copy, Default)]
 pub struct TwoloopScore {
   i: u32,
@@ -50,10 +55,12 @@ extern "C" {
   fn rnamc_params_field(idx: u32, name: *mut *const c_char, byte_offset: *mut u64, count: *mut u64) -> c_int;
   fn rnamc_params_set_special_hairpins(p: *mut c_void, n: u32, seqs: *const u8, lens: *const u8, scores: *const f32) -> c_int;
   fn rnamc_params_set_hairpin_limits(p: *mut c_void, min_hairpin_len: u32, max_hairpin_len_extrapolation: u32, min_hairpin_len_extrapolation: u32) -> c_int;
-  fn rnamc_ctx_create(params: *const c_void, device: c_int, workspace_bytes: u64, out: *mut *mut RnamcCtx) -> c_int;
-  fn rnamc_ctx_set_params(ctx: *mut RnamcCtx, params: *const c_void) -> c_int;
+  fn rnamc_pool_create(params: *const c_void, devices: *const c_int, n_devices: u32, workspace_bytes: u64, out: *mut *mut RnamcPool) -> c_int;
+  fn rnamc_pool_ctx(pool: *mut RnamcPool, idx: u32) -> *mut RnamcCtx;
+  fn rnamc_pool_set_params(pool: *mut RnamcPool, params: *const c_void) -> c_int;
+  fn rnamc_pool_set(pool: *mut RnamcPool, name: *const c_char, value: i64) -> c_int;
   fn rnamc_bpp_len(n: u32) -> u64;
-  fn rnamc_bpp_batch(ctx: *mut RnamcCtx, n_seqs: u32, bases: *const u8, offsets: *const u64, uses_contra_model: c_int, allows_short_hairpins: c_int, bpp: *mut f32, out_offsets: *const u64, log_partition: *mut f32) -> c_int;
+  fn rnamc_bpp_batch_multi(pool: *mut RnamcPool, n_seqs: u32, bases: *const u8, offsets: *const u64, uses_contra_model: c_int, allows_short_hairpins: c_int, bpp: *mut f32, out_offsets: *const u64, log_partition: *mut f32) -> c_int;
   fn rnamc_fold_scores(ctx: *mut RnamcCtx, bases: *const u8, n: u32, uses_contra_model: c_int, allows_short_hairpins: c_int, hairpin_scores: *mut f32, multibranch_close_scores: *mut f32, accessible_scores: *mut f32, twoloop_scores: *mut TwoloopScore, twoloop_cap: u64, twoloop_count: *mut u64) -> c_int;
 }
 
@@ -71,10 +78,11 @@ fn check(status: c_int, what: &str) {
   }
 }
 
-// One device context per process (workspace and staging buffers are reused across calls);
-// `key` is the hash of the FoldScoreSets contents its tables were built from.
+// One pool per process: a device context (tables, workspace, streams) on EVERY visible GPU,
+// reused across calls; `key` is the hash of the FoldScoreSets contents its tables were built
+// from.  A batch is sharded over the pool's devices inside librnamc (rnamc_bpp_batch_multi).
 struct State {
-  ctx: *mut RnamcCtx,
+  pool: *mut RnamcPool,
   key: u64,
 }
 unsafe impl Send for State {}
@@ -95,7 +103,7 @@ fn content_key(f: &FoldScoreSets) -> u64 {
 // Runs `f` with a context whose tables are `fold_score_sets`.  The lock is held across the
 // FFI call, so a caller on another thread with a different set cannot swap the tables under
 // it (calls on one context are serialised inside librnamc anyway).
-fn with_context<R>(fold_score_sets: &FoldScoreSets, f: impl FnOnce(*mut RnamcCtx) -> R) -> R {
+fn with_pool<R>(fold_score_sets: &FoldScoreSets, f: impl FnOnce(*mut RnamcPool) -> R) -> R {
   let key = content_key(fold_score_sets);
   let mut guard = STATE.lock().unwrap_or_else(|e| e.into_inner());
   let stale = match guard.as_ref() {
@@ -107,17 +115,30 @@ fn with_context<R>(fold_score_sets: &FoldScoreSets, f: impl FnOnce(*mut RnamcCtx
     let p = params.as_ptr() as *const c_void;
     match guard.as_mut() {
       Some(st) => {
-        check(unsafe { rnamc_ctx_set_params(st.ctx, p) }, "rnamc_ctx_set_params");
+        check(unsafe { rnamc_pool_set_params(st.pool, p) }, "rnamc_pool_set_params");
         st.key = key;
       }
       None => {
-        let mut ctx = std::ptr::null_mut();
-        check(unsafe { rnamc_ctx_create(p, -1, 0, &mut ctx) }, "rnamc_ctx_create");
-        *guard = Some(State { ctx, key });
+        let mut pool = std::ptr::null_mut();
+        // n_devices = 0: one context per visible GPU
+        check(unsafe { rnamc_pool_create(p, std::ptr::null(), 0, 0, &mut pool) }, "rnamc_pool_create");
+        // RNA_ALGOS_SUMMATION_MODE=1 opts in to the tree-order sums (about 10x faster on a lone
+        // long sequence; NOT bit-comparable with the reference CPU path: include/rnamc.h,
+        // rnamc_ctx_set).  The default, 0, is the reference's own summation order.
+        if let Ok(v) = std::env::var("RNA_ALGOS_SUMMATION_MODE") {
+          let name = std::ffi::CString::new("summation_mode").unwrap();
+          check(unsafe { rnamc_pool_set(pool, name.as_ptr(), v.parse::<i64>().unwrap_or(0)) }, "rnamc_pool_set");
+        }
+        *guard = Some(State { pool, key });
       }
     }
   }
-  f(guard.as_ref().unwrap().ctx)
+  f(guard.as_ref().unwrap().pool)
+}
+
+// the first context of the pool, for the per-sequence entries (rnamc_fold_scores)
+fn with_context<R>(fold_score_sets: &FoldScoreSets, f: impl FnOnce(*mut RnamcCtx) -> R) -> R {
+  with_pool(fold_score_sets, |pool| f(unsafe { rnamc_pool_ctx(pool, 0) }))
 }
 
 // Fills a rnamc_params block: every f32 table by name (rnamc_params_field gives name, byte
@@ -254,10 +275,11 @@ fn unpack_probs<T: HashIndex>(packed: &[f32], n: usize) -> SparseProbMat<T> {
   basepair_probs
 }
 
-// The whole FASTA in one device batch: what src/bin/mccaskill_algo.rs:58-93 and
-// src/bin/centroid_fold.rs:119-132 do with one pool task per record.  Called from that pool
-// instead, every per-sequence call would serialise on the context and run as a latency-bound
-// group of one.  Returns the `.0` of mccaskill_algo per record (the binaries discard `.1`).
+// The whole FASTA in one call, sharded over every visible GPU: what
+// src/bin/mccaskill_algo.rs:58-93 and src/bin/centroid_fold.rs:119-132 do with one pool task
+// per record on all cores.  Called from that pool instead, every per-sequence call would
+// serialise on the pool and run as a latency-bound group of one on one device.  Returns the
+// `.0` of mccaskill_algo per record (the binaries discard `.1`).
 pub fn mccaskill_algo_batch<T>(
   seqs: &[SeqSlice],
   uses_contra_model: bool,
@@ -275,11 +297,11 @@ where
     out_offsets.push(out_offsets.last().unwrap() + unsafe { rnamc_bpp_len(seq.len() as u32) });
   }
   let mut packed = vec![0f32; (*out_offsets.last().unwrap() as usize).max(1)];
-  with_context(fold_score_sets, |ctx| {
+  with_pool(fold_score_sets, |pool| {
     check(
       unsafe {
-        rnamc_bpp_batch(
-          ctx,
+        rnamc_bpp_batch_multi(
+          pool,
           seqs.len() as u32,
           bases.as_ptr(),
           offsets.as_ptr(),
@@ -290,7 +312,7 @@ where
           std::ptr::null_mut(),
         )
       },
-      "rnamc_bpp_batch",
+      "rnamc_bpp_batch_multi",
     )
   });
   seqs

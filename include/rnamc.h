@@ -35,7 +35,9 @@
 extern "C" {
 #endif
 
-#define RNAMC_ABI_VERSION 2u
+/* 3: summation_mode knob (tree-order sums), rnamc_ctx_stats (sized copy), multi-device batch
+ *    entry rnamc_bpp_batch_multi; rnamc_params itself is unchanged since 2 */
+#define RNAMC_ABI_VERSION 3u
 
 /* Compile-time limits.  In the reference these are constants of rna-ss-params
  * (recalled values): NUM_BASES, MAX_2LOOP_LEN (src/utils.rs:308),
@@ -215,10 +217,27 @@ void rnamc_ctx_destroy(rnamc_ctx* ctx);
  * set is trainable (src/utils.rs:91-119): a host mirror that caches a context calls this
  * whenever the contents of the caller's set differ from the ones last uploaded. */
 int rnamc_ctx_set_params(rnamc_ctx* ctx, const rnamc_params* params);
-/* Tuning knobs (all optional): name in {"group_max_seqs","group_max_nt","group_ws_bytes",
- * "block_threads","fuse_inside","dual_outside","dual_min_cells","dual_max_diag",
- * "order_inside","order_outside","head_lds","head_wmax_in","head_wmax_out","latency_mode",
- * "lat_max_cells","lat_inside","lat_inside_waves","lat_e_waves","lat_pairs","lat_merge","lat_zr_ahead","profile"}; returns RNAMC_ERR_INVALID_ARG for unknown names. */
+/* Knobs; returns RNAMC_ERR_INVALID_ARG for unknown names or values.
+ *
+ * "summation_mode" selects how every logsumexp sum of the sweep is evaluated:
+ *   0 (default) reference order: each fold runs in the reference's k order with its cubic
+ *     ln_exp_1p / expf pieces (src/utils.rs:579-655) — bit-identical to the reference CPU path
+ *     (the parity gate; north_star's <= 1e-6);
+ *   1 tree order: order-free sums (every lane keeps a running max and a sum of exp, merged by
+ *     wave and LDS reductions; hardware exp2 / log2), the reference's recurrences with the
+ *     cell-independent Theta(n^3) loops turned into prefix recurrences
+ *     (rna_algos_amd/csrc/rnamc_tree.hip).  NOT bit-comparable with the reference: the
+ *     reference's fold is approximate and order-dependent, so this mode differs from it by the
+ *     reference's own error (measured max |dp| 1e-3 at n = 76, 7e-3 ... 2e-2 at n = 4096; ln Z by
+ *     3e-2 ... 1e-1 at n = 4096) while agreeing with the exact (f64) value of the same
+ *     recurrences to f32 rounding (|dp| < 1e-4 at n = 1024).  Key sets are identical.  About
+ *     ten times faster than mode 0 on a lone long sequence.  rnamc_fold_scores and
+ *     rnamc_debug_fetch always use mode 0.
+ * Tuning (all optional): "group_max_seqs","group_max_nt","group_ws_bytes","block_threads",
+ * "fuse_inside","dual_outside","dual_min_cells","dual_max_diag","order_inside","order_outside",
+ * "latency_mode","lat_max_cells","lat_inside","lat_inside_waves","lat_e_waves","lat_pairs",
+ * "lat_merge","lat_zr_ahead","profile"; tree-order mode: "tree_two" (two anti-diagonals per
+ * launch, default 1), "tree_tpc" (threads per cell: 64 / 256 / 1024, 0 = by diagonal size). */
 int rnamc_ctx_set(rnamc_ctx* ctx, const char* name, int64_t value);
 
 /* mccaskill_algo over a batch (src/mccaskill_algo.rs:247-280 for each record, as
@@ -229,7 +248,8 @@ int rnamc_ctx_set(rnamc_ctx* ctx, const char* name, int64_t value);
  *                bpp + out_offsets[s]; entry (i,j) at rnamc_bpp_index; a pair
  *                absent from the reference's SparseProbMat holds -1.0f
  *   log_partition  n_seqs f32: sums_external[0][n-1] (may be NULL)
- * The summation order of every logsumexp fold is the reference's. */
+ * The summation order of every logsumexp fold is the reference's unless the context's
+ * "summation_mode" knob says otherwise (rnamc_ctx_set). */
 int rnamc_bpp_batch(rnamc_ctx* ctx, uint32_t n_seqs, const uint8_t* bases,
                     const uint64_t* offsets, int uses_contra_model, int allows_short_hairpins,
                     float* bpp, const uint64_t* out_offsets, float* log_partition);
@@ -242,6 +262,41 @@ int rnamc_bpp_batch_device(rnamc_ctx* ctx, uint32_t n_seqs, const uint8_t* d_bas
                            const uint64_t* offsets, int uses_contra_model,
                            int allows_short_hairpins, float* d_bpp, const uint64_t* out_offsets,
                            float* d_log_partition, void* hip_stream);
+
+/* ------------------------------------------------------------------------- */
+/* The batch over SEVERAL devices: what the reference's binaries do with one pool task per
+ * record on all cores (src/bin/mccaskill_algo.rs:58-93, src/bin/centroid_fold.rs:119-132).
+ * A pool owns one device context (tables, workspace, streams) per listed device and one host
+ * thread per context during a call.  The batch is cut into as many shards as there are
+ * contexts — contiguous bands of the cost-sorted batch with equal total cost under the
+ * measured sweep model (rnamc_shard_plan) — every shard runs through rnamc_bpp_batch of its
+ * own context and writes straight into the caller's host triangles.  Sequences are never
+ * split; there is no collective and no device-to-device traffic.
+ *   devices / n_devices  HIP device ordinals, one context each (an ordinal may repeat: several
+ *                        contexts on one GPU); n_devices == 0 = every visible device
+ *   workspace_bytes      per context, as in rnamc_ctx_create */
+typedef struct rnamc_pool rnamc_pool;
+int rnamc_pool_create(const rnamc_params* params, const int* devices, uint32_t n_devices,
+                      uint64_t workspace_bytes, rnamc_pool** out);
+void rnamc_pool_destroy(rnamc_pool* pool);
+uint32_t rnamc_pool_size(const rnamc_pool* pool);
+/* context idx of the pool (owned by the pool), e.g. for rnamc_ctx_stats; NULL past the end */
+rnamc_ctx* rnamc_pool_ctx(rnamc_pool* pool, uint32_t idx);
+/* rnamc_ctx_set_params / rnamc_ctx_set on every context of the pool */
+int rnamc_pool_set_params(rnamc_pool* pool, const rnamc_params* params);
+int rnamc_pool_set(rnamc_pool* pool, const char* name, int64_t value);
+/* Arguments as rnamc_bpp_batch.  The whole batch is validated first: a bad record fails the
+ * call with its status before any device is touched.  A device-side failure of one shard is
+ * returned once the other shards have finished (no buffer is left in use). */
+int rnamc_bpp_batch_multi(rnamc_pool* pool, uint32_t n_seqs, const uint8_t* bases,
+                          const uint64_t* offsets, int uses_contra_model,
+                          int allows_short_hairpins, float* bpp, const uint64_t* out_offsets,
+                          float* log_partition);
+/* The partition rnamc_bpp_batch_multi uses (host only, no device needed): shard_of_seq[s] in
+ * 0 .. n_shards-1.  Shard k holds a band of the batch sorted by length (longest first,
+ * stable); cuts lie where the running cost a*n(n^2-1)/6 + b*n^2 reaches k/n_shards of the total. */
+int rnamc_shard_plan(uint32_t n_seqs, const uint64_t* offsets, uint32_t n_shards,
+                     uint32_t* shard_of_seq);
 
 /* Per-kernel accounting of the last batch call on this ctx (launch counts and
  * device time by HIP events on the launch stream; the latter only when
@@ -269,6 +324,10 @@ typedef struct rnamc_batch_stats {
   double ms_outside_head;
 } rnamc_batch_stats;
 int rnamc_ctx_last_stats(rnamc_ctx* ctx, rnamc_batch_stats* out);
+/* The same with the caller's idea of the struct size: copies min(out_bytes, sizeof) bytes, so a
+ * binding compiled against an older (shorter) rnamc_batch_stats is never overrun.  Returns the
+ * library's sizeof(rnamc_batch_stats) through *lib_bytes (may be NULL). */
+int rnamc_ctx_stats(rnamc_ctx* ctx, void* out, uint64_t out_bytes, uint64_t* lib_bytes);
 
 /* Debug / test hook: copy one DP matrix of sequence `seq_idx` of the LAST group
  * of the last batch call back to the host as a dense n*n row-major f32 matrix

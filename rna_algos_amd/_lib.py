@@ -23,9 +23,11 @@ SYMBOLS = [
     "rnamc_params_save", "rnamc_params_load", "rnamc_params_field",
     "rnamc_params_set_special_hairpins", "rnamc_params_set_hairpin_limits",
     "rnamc_ctx_create", "rnamc_ctx_destroy", "rnamc_ctx_set", "rnamc_ctx_set_params",
-    "rnamc_bpp_batch", "rnamc_bpp_batch_device", "rnamc_ctx_last_stats",
+    "rnamc_bpp_batch", "rnamc_bpp_batch_device", "rnamc_ctx_last_stats", "rnamc_ctx_stats",
     "rnamc_debug_fetch", "rnamc_fold_scores", "rnamc_centroid_fold",
     "rnamc_align_scores_new", "rnamc_align_scores_transfer", "rnamc_durbin_batch",
+    "rnamc_pool_create", "rnamc_pool_destroy", "rnamc_pool_size", "rnamc_pool_ctx",
+    "rnamc_pool_set_params", "rnamc_pool_set", "rnamc_bpp_batch_multi", "rnamc_shard_plan",
 ]
 
 
@@ -55,10 +57,37 @@ class BatchStats(C.Structure):
 _lib = None
 
 
+def _preload_torch_hip():
+    """One HIP runtime per process.  torch bundles its own libamdhip64.so / libhsa-runtime64.so;
+    librnamc.so needs `libamdhip64.so.7`.  If librnamc is loaded first it brings in /opt/rocm's
+    runtime, and a later `import torch` adds its bundled pair as a second HSA runtime, which
+    then sees no GPU ("No HIP GPUs are available").  Loading torch's copy first (without
+    importing torch) lets the dynamic loader satisfy librnamc's NEEDED entry with it (same
+    SONAME) and torch find its own library already mapped.  RNAMC_NO_TORCH_PRELOAD=1 skips this
+    (processes that never use torch and want /opt/rocm's runtime)."""
+    import importlib.util
+    import sys
+    if os.environ.get("RNAMC_NO_TORCH_PRELOAD") == "1" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _lib
     if _lib is not None:
         return _lib
+    _preload_torch_hip()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -94,6 +123,18 @@ def lib():
     L.rnamc_bpp_batch.argtypes = [vp, C.c_uint32, vp, vp, C.c_int, C.c_int, vp, vp, vp]
     L.rnamc_bpp_batch_device.argtypes = [vp, C.c_uint32, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.rnamc_ctx_last_stats.argtypes = [vp, C.POINTER(BatchStats)]
+    L.rnamc_ctx_stats.argtypes = [vp, vp, C.c_uint64, u64p]
+    L.rnamc_pool_create.argtypes = [vp, vp, C.c_uint32, C.c_uint64, C.POINTER(vp)]
+    L.rnamc_pool_destroy.argtypes = [vp]
+    L.rnamc_pool_destroy.restype = None
+    L.rnamc_pool_size.argtypes = [vp]
+    L.rnamc_pool_size.restype = C.c_uint32
+    L.rnamc_pool_ctx.argtypes = [vp, C.c_uint32]
+    L.rnamc_pool_ctx.restype = vp
+    L.rnamc_pool_set_params.argtypes = [vp, vp]
+    L.rnamc_pool_set.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.rnamc_bpp_batch_multi.argtypes = [vp, C.c_uint32, vp, vp, C.c_int, C.c_int, vp, vp, vp]
+    L.rnamc_shard_plan.argtypes = [C.c_uint32, vp, C.c_uint32, vp]
     L.rnamc_debug_fetch.argtypes = [vp, C.c_uint32, C.c_int, vp]
     L.rnamc_fold_scores.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, vp, vp, vp, vp,
                                     C.c_uint64, u64p]

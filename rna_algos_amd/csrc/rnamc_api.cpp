@@ -49,6 +49,8 @@ struct rnamc_ctx {
   TreeSeq* d_tseqs = nullptr;  // descriptors of the tree-order mode
   uint64_t tseqs_cap = 0;
   std::vector<TreeSeq> h_tseqs;  // (host copy: source of an async upload, must outlive it)
+  TreeTabs* d_tree_tabs = nullptr;  // 2-loop tables of the tree-order mode (built from the params)
+  bool tree_tabs_valid = false;
   // host-buffer entry: device staging of bases / result / log partition (grow-only)
   // The result is staged per lock-step GROUP in two alternating device buffers: group g's
   // D2H (copy stream, pinned bounce chunks, a host thread) runs while group g+1 sweeps.
@@ -70,6 +72,9 @@ struct rnamc_ctx {
   // 0: every logsumexp fold in the reference's order (the parity gate); 1: order-free sums
   // (rnamc_tree.hip), not bit-comparable with the reference
   int64_t summation_mode = 0;
+  int64_t tree_tpc = 0;  // tree mode: threads per cell (64 / 256 / 1024), 0 = by diagonal size
+  int64_t tree_two = 1;  // tree mode: two diagonals per launch
+  int64_t tree_debug = 0;  // (RNAMC_DEBUG_KNOBS builds: bit 0 no 2-loops, 1 no products, 2 empty kernels)
   int64_t group_max_seqs = 8192;
   int64_t group_max_nt = 2ll << 20;  // a group holds ~2M nucleotides (or 64 GB of DP state)
   int64_t group_ws_bytes = 64ll << 30;
@@ -710,6 +715,86 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
   return RNAMC_OK;
 }
 
+// Tables of the tree-order 2-loop scorer (TreeTabs, rnamc_device.h), from the parameter block.
+// Turner: get_bulge_score / get_interior_score (src/utils.rs:234-321, 331-366); CONTRAfold:
+// get_bulge_score_contra / get_interior_score_contra (456-520) + the enclosed pair's
+// base-pair score (src/mccaskill_algo.rs:441).
+void build_tree_tabs(const rnamc_params& P, TreeTabs& T) {
+  std::memset(&T, 0, sizeof(T));
+  const rnamc_turner_scores& t = P.turner;
+  const rnamc_fold_score_sets& f = P.contra;
+  auto pen = [&](int a, int b) { return augu(a, b) ? t.helix_augu_end_penalty : 0.f; };
+  const float(*tmx[4])[4][4][4] = {nullptr, t.terminal_mismatch_scores_1xmany,
+                                   t.terminal_mismatch_scores_2x3, t.terminal_mismatch_scores_interior};
+  for (int c = 0; c < 4; c++)
+    for (int x = 0; x < 256; x++) {
+      const int b0 = x & 3, b1 = (x >> 2) & 3, b2 = (x >> 4) & 3, b3 = (x >> 6) & 3;
+      {  // inside: x = m3 + 4 ak + 16 al + 64 m2
+        const int m3 = b0, ak = b1, al = b2, m2 = b3;
+        T.in[0][c][x] = c == 0 ? pen(ak, al) : tmx[c][al][ak][m2][m3] + pen(ak, al);
+        T.in[1][c][x] = (f.helix_close_scores[al][ak] + f.terminal_mismatch_scores[al][ak][m2][m3]) +
+                        f.basepair_scores[ak][al];
+      }
+      {  // outside: x = ck + 4 x1 + 16 y1 + 64 cl
+        const int ck = b0, x1 = b1, y1 = b2, cl = b3;
+        T.out[0][c][x] = c == 0 ? pen(ck, cl) : tmx[c][ck][cl][x1][y1] + pen(ck, cl);
+        T.out[1][c][x] = f.helix_close_scores[ck][cl] + f.terminal_mismatch_scores[ck][cl][x1][y1];
+      }
+    }
+  for (uint32_t p = 0; p < 512; p++) {
+    const uint32_t r = p >> 5, c = p & 31u;
+    const bool first = c < 31u - r;
+    const uint32_t a = first ? r : 30u - r, b = first ? c : c - (31u - r);
+    const bool valid = r < 15u || c < 16u;
+    const uint32_t len = a + b, diff = a > b ? a - b : b - a;
+    const bool bulge = (a == 0u) != (b == 0u);
+    for (int m = 0; m < 2; m++) {
+      uint32_t kind = valid ? 1u : 0u, cls = 0;
+      float lv = 0.f;
+      if (valid) {
+        const bool special = m == 0 ? (len == 0u || (bulge && len == 1u) || (a >= 1u && a <= 2u && b >= 1u && b <= 2u))
+                                    : (a <= 1u && b <= 1u);
+        if (special) {
+          kind = 2u;
+        } else if (m == 0) {
+          if (bulge) {
+            cls = 0;
+            lv = t.bulge_scores_init[len];
+          } else {
+            cls = (a == 1u || b == 1u) ? 1u : (((a == 2u && b == 3u) || (a == 3u && b == 2u)) ? 2u : 3u);
+            const float nin = t.ninio_coeff * static_cast<float>(diff);
+            lv = t.interior_scores_init[len] + (nin > t.ninio_max ? nin : t.ninio_max);
+          }
+        } else {
+          if (bulge) {
+            lv = f.bulge_scores_len_cumulative[len - 1u];
+          } else {
+            const float s0 = (a == b) ? f.interior_scores_symmetric_cumulative[a - 1u]
+                                      : f.interior_scores_asymmetric_cumulative[diff - 1u];
+            const float se = (a <= RNAMC_MAX_INTERIOR_EXPLICIT && b <= RNAMC_MAX_INTERIOR_EXPLICIT)
+                                 ? f.interior_scores_explicit[a - 1u][b - 1u]
+                                 : 0.f;
+            lv = (s0 + se) + f.interior_scores_len_cumulative[len - 2u];
+          }
+        }
+      }
+      T.len[m][p] = lv;
+      T.slot[m][p] = a | (b << 8) | (cls << 16) | (kind << 24);
+    }
+  }
+}
+
+int ensure_tree_tabs(rnamc_ctx* c, hipStream_t st) {
+  if (c->tree_tabs_valid && c->d_tree_tabs) return RNAMC_OK;
+  if (!c->d_tree_tabs) HIPCHK(hipMalloc(&c->d_tree_tabs, sizeof(TreeTabs)));
+  static thread_local TreeTabs tabs;  // (16 KB: not on the stack; the copy below is synchronous)
+  build_tree_tabs(c->host_params, tabs);
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipMemcpy(c->d_tree_tabs, &tabs, sizeof(TreeTabs), hipMemcpyHostToDevice));
+  c->tree_tabs_valid = true;
+  return RNAMC_OK;
+}
+
 // Tree-order summation mode (rnamc_tree.hip): same grouping and per-diagonal sweep, dense
 // n x n matrices, one workgroup per cell.  Fills c->descs / group_* like run_batch so that the
 // host-buffer entry's drain thread works unchanged.
@@ -732,6 +817,8 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
   }
   int rc = ensure_hp_init(c, max_n);
   if (rc) return rc;
+  rc = ensure_tree_tabs(c, st);
+  if (rc) return rc;
   std::vector<uint32_t> order(n_seqs);
   std::iota(order.begin(), order.end(), 0u);
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
@@ -752,7 +839,9 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
       ts.n = n;
       ts.ld = ((n + 31u) & ~31u) + 32u;
       ts.msz = ((static_cast<uint64_t>(ts.ld) * n + 63ull) & ~63ull) + 64ull;
-      const uint64_t need = ts.msz * T_COUNT + 2ull * ((static_cast<uint64_t>(n) + 64ull + 63ull) & ~63ull);
+      const uint64_t vec = (static_cast<uint64_t>(n) + 64ull + 63ull) & ~63ull;
+      ts.pk_words = static_cast<uint32_t>(((static_cast<uint64_t>(n) + 160) / 16 + 4 + 63) & ~63ull);
+      const uint64_t need = ts.msz * T_COUNT + 2ull * vec + ts.pk_words;
       if (cnt > 0 && (cnt >= static_cast<uint32_t>(c->group_max_seqs) ||
                       cur_nt + n > static_cast<uint64_t>(c->group_max_nt) ||
                       cur + need > ws_cap_floats)) {
@@ -764,6 +853,7 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
       if (cnt == 0) c->group_begin.push_back(static_cast<uint32_t>(c->descs.size()));
       ts.seq_off = offsets[s];
       ts.ws_off = cur;
+      ts.pk_off = cur + ts.msz * T_COUNT + 2ull * vec;
       ts.out_off = hooks ? cur_out : out_offsets[s];
       ts.batch_idx = s;
       tseqs.push_back(ts);
@@ -826,8 +916,12 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
     }
     b.log_partition = d_logz;
     b.params = c->d_params;
+    b.tabs = c->d_tree_tabs;
     b.hp_init = c->d_hp_init;
     b.allows_short_hairpins = allows_short ? 1 : 0;
+#ifdef RNAMC_DEBUG_KNOBS
+    b.debug = static_cast<int>(c->tree_debug);
+#endif
     auto active = [&](uint32_t d) {  // sequences with n > d form a prefix of the group
       uint32_t lo = 0, hi = nseq;
       while (lo < hi) {
@@ -839,15 +933,30 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 0], st));
     launch_tree_init(b, nseq, gmax, contra, 0, st);
     c->stats.launches_other++;
-    for (uint32_t d = dmin_in; d < gmax; d++) {
-      launch_tree_inside(b, contra, d, gmax, active(d), st);
+    const bool two = c->tree_two != 0;
+    for (uint32_t d = dmin_in; d < gmax; d += two ? 2 : 1) {
+      launch_tree_inside(b, contra, d, gmax, active(d), c->tree_tpc, two, st);
       c->stats.launches_inside++;
     }
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 1], st));
     launch_tree_init(b, nseq, gmax, contra, 1, st);
     c->stats.launches_other++;
+    if (two) {
+      // pairs (d+1, d) from the top; the lowest diagonal alone when their number is odd
+      int64_t d = static_cast<int64_t>(gmax) - 1;
+      for (; d - 1 >= static_cast<int64_t>(dmin_out); d -= 2) {
+        launch_tree_outside(b, contra, static_cast<uint32_t>(d - 1), gmax, active(static_cast<uint32_t>(d - 1)),
+                            c->tree_tpc, true, st);
+        c->stats.launches_outside++;
+      }
+      if (d >= static_cast<int64_t>(dmin_out)) {
+        launch_tree_outside(b, contra, static_cast<uint32_t>(d), gmax, active(static_cast<uint32_t>(d)),
+                            c->tree_tpc, false, st);
+        c->stats.launches_outside++;
+      }
+    } else
     for (uint32_t d = gmax; d-- > dmin_out;) {
-      launch_tree_outside(b, contra, d, gmax, active(d), st);
+      launch_tree_outside(b, contra, d, gmax, active(d), c->tree_tpc, false, st);
       c->stats.launches_outside++;
     }
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 2], st));
@@ -1046,6 +1155,7 @@ void rnamc_ctx_destroy(rnamc_ctx* c) {
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_seqs) (void)hipFree(c->d_seqs);
     if (c->d_tseqs) (void)hipFree(c->d_tseqs);
+    if (c->d_tree_tabs) (void)hipFree(c->d_tree_tabs);
   }
   delete c;
 }
@@ -1060,6 +1170,7 @@ int rnamc_ctx_set_params(rnamc_ctx* c, const rnamc_params* params) {
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(c->d_params, params, sizeof(rnamc_params), hipMemcpyHostToDevice));
   c->host_params = *params;
+  c->tree_tabs_valid = false;
   c->hp_init_len = 0;  // the hairpin extrapolation table is derived from the Turner block
   c->fs_contra = c->fs_short = -1;
   c->fs_bases.clear();
@@ -1072,6 +1183,10 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
   const std::string k(name);
   if (k == "summation_mode" && (value == 0 || value == 1)) {
     c->summation_mode = value;
+  } else if (k == "tree_two") {
+    c->tree_two = value;
+  } else if (k == "tree_tpc" && (value == 0 || value == 64 || value == 256 || value == 1024)) {
+    c->tree_tpc = value;
   } else if (k == "group_max_seqs" && value >= 1) {
     c->group_max_seqs = std::min<int64_t>(value, 65535);
   } else if (k == "group_max_nt" && value >= 1) {
@@ -1123,6 +1238,8 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
 #ifdef RNAMC_DEBUG_KNOBS  // result-changing: timing experiments only, never in a release build
   } else if (k == "debug_roles") {
     c->debug_roles = value;
+  } else if (k == "tree_debug") {
+    c->tree_debug = value;
 #endif
   } else {
     return RNAMC_ERR_INVALID_ARG;
@@ -1342,6 +1459,14 @@ int rnamc_ctx_last_stats(rnamc_ctx* c, rnamc_batch_stats* out) {
   return RNAMC_OK;
 }
 
+int rnamc_ctx_stats(rnamc_ctx* c, void* out, uint64_t out_bytes, uint64_t* lib_bytes) {
+  if (!c || (!out && out_bytes)) return RNAMC_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  if (lib_bytes) *lib_bytes = sizeof(rnamc_batch_stats);
+  std::memcpy(out, &c->stats, static_cast<size_t>(std::min<uint64_t>(out_bytes, sizeof(rnamc_batch_stats))));
+  return RNAMC_OK;
+}
+
 int rnamc_debug_fetch(rnamc_ctx* c, uint32_t seq_idx, int which, float* out_nxn) {
   if (!c || !out_nxn) return RNAMC_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lock(c->mu);
@@ -1496,7 +1621,8 @@ int rnamc_durbin_batch(rnamc_ctx* c, const rnamc_align_scores* scores, uint32_t 
       dp.n1 = static_cast<uint32_t>(offsets[pair_a[p] + 1] - offsets[pair_a[p]]);
       dp.n2 = static_cast<uint32_t>(offsets[pair_b[p] + 1] - offsets[pair_b[p]]);
       const uint64_t cells = static_cast<uint64_t>(dp.n1) * dp.n2;
-      if (!chunk.empty() && ws + 6 * cells > ws_cap) break;
+      // (k_durbin_probs indexes pairs through blockIdx.y: at most 65535 per launch)
+      if (!chunk.empty() && (ws + 6 * cells > ws_cap || chunk.size() >= 65535u)) break;
       dp.a_off = offsets[pair_a[p]] - base_lo;
       dp.b_off = offsets[pair_b[p]] - base_lo;
       dp.ws_off = ws;

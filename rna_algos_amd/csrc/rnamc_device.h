@@ -93,7 +93,19 @@ enum TreeMat : int {
   T_ZRM = 5,  // sums_rightmost_basepairs_multibranch         col | outside: R = Pm (+) Pm2, col
   T_QM = 6,   // sums_multibranch                             row | outside: probs_multibranch2, row
   T_U = 7,    // column prefix of Zr_mb (first fold of L_c)   col | outside: column prefix of Pm, col
-  T_COUNT = 8
+  T_PQ = 8,   // outside: {log bpp, sums_close} of a finished pair, interleaved float2, row (two slots)
+  T_COUNT = 10
+};
+// Tables of the tree-order 2-loop scorer, derived from rnamc_params on the host
+// (rnamc_api.cpp, build_tree_tabs).  Model index 0 Turner, 1 CONTRAfold.  A generic 2-loop
+// (bulge or interior loop that is not one of the few small explicit ones) scores as
+//   len[slot] + side_of_the_fixed_pair[cls] + table[cls][bases of the varying pair]
+// with cls in {0 bulge, 1 1 x many, 2 2 x 3, 3 other interior} (CONTRAfold: rows alike).
+struct TreeTabs {
+  float in[2][4][256];    // varying = enclosed pair (inside sweep): [cls][m3 + 4 ak + 16 al + 64 m2]
+  float out[2][4][256];   // varying = closing pair (outside sweep): [cls][ck + 4 x1 + 16 y1 + 64 cl]
+  float len[2][512];      // per probe slot: the length-dependent part
+  uint32_t slot[2][512];  // a | b << 8 | cls << 16 | kind << 24; kind 0 no probe, 1 generic, 2 special
 };
 struct TreeSeq {
   uint32_t n, ld;
@@ -102,8 +114,9 @@ struct TreeSeq {
   uint64_t ws_off;    // float offset of the first matrix; after the T_COUNT matrices come the
                       // vectors Z(0,.) and Z(.,n-1), n + 64 floats each
   uint64_t out_off;   // float offset of the packed bpp triangle in the output
+  uint64_t pk_off;    // float offset of the 2-bit packed copy of the bases (pk_words words)
+  uint32_t pk_words;
   uint32_t batch_idx;
-  uint32_t pad_;
 };
 struct TreeBatch {
   const TreeSeq* seqs;  // descriptors of the group (device memory)
@@ -114,16 +127,20 @@ struct TreeBatch {
   float* out;
   float* log_partition;
   const rnamc_params* params;
+  const TreeTabs* tabs;
   const float* hp_init;
   int allows_short_hairpins;
+  int debug;  // timing experiments (builds with -DRNAMC_DEBUG_KNOBS only; 0 otherwise)
 };
 // what = 0: everything before the inside sweep; 1: the four reused slots before the outside sweep
 void launch_tree_init(const TreeBatch& b, uint32_t nseq, uint32_t max_n, bool contra, int what,
                       hipStream_t st);
+// tpc_knob: threads per cell (64, 256, 1024), anything else = chosen by the diagonal's cells;
+// two: diagonals d and d+1 in one launch (inside: d then d+1; outside: d+1 then d)
 void launch_tree_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
-                        hipStream_t st);
+                        int64_t tpc_knob, bool two, hipStream_t st);
 void launch_tree_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
-                         hipStream_t st);
+                         int64_t tpc_knob, bool two, hipStream_t st);
 void launch_tree_finalize(const TreeBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st);
 
 }  // namespace rnamc

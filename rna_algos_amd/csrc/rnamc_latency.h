@@ -644,49 +644,7 @@ struct Win2 {
   uint8_t left[40], right[40];
 };
 
-__device__ __forceinline__ float turner_twoloop_flat(const rnamc_turner_scores& t, uint32_t a,
-                                                     uint32_t b, int ci, int cj, int x1, int x2,
-                                                     int y1, int y2, int ak, int al, int m2, int m3) {
-  const bool bulge = (a == 0u) != (b == 0u);
-  const uint32_t len = a + b;
-  const bool stack = len == 0u, bulge1 = bulge && len == 1u, bulgeN = bulge && len > 1u;
-  const bool i11 = a == 1u && b == 1u, i12 = a == 1u && b == 2u, i21 = a == 2u && b == 1u,
-             i22 = a == 2u && b == 2u;
-  const bool generic = !(stack || bulge || i11 || i12 || i21 || i22);
-  // primary entry
-  const float* tmx = (a == 1u || b == 1u) ? &t.terminal_mismatch_scores_1xmany[0][0][0][0]
-                     : ((a == 2u && b == 3u) || (a == 3u && b == 2u))
-                         ? &t.terminal_mismatch_scores_2x3[0][0][0][0]
-                         : &t.terminal_mismatch_scores_interior[0][0][0][0];
-  const float* pa;
-  if (stack || bulge1) {
-    pa = &t.stack_scores[ci][cj][ak][al];
-  } else if (i11) {
-    pa = &t.interior_scores_1x1[ci][cj][x1][y1][ak][al];
-  } else if (i12) {
-    pa = &t.interior_scores_1x2[ci][cj][x1][y1][y2][ak][al];
-  } else if (i21) {
-    pa = &t.interior_scores_1x2[al][ak][y1][x2][x1][cj][ci];
-  } else if (i22) {
-    pa = &t.interior_scores_2x2[ci][cj][x1][y1][x2][y2][ak][al];
-  } else {
-    pa = tmx + ((ci * 4 + cj) * 4 + x1) * 4 + y1;  // (bulgeN: read, not used)
-  }
-  const float* pb = tmx + ((al * 4 + ak) * 4 + m2) * 4 + m3;
-  const float* pc = bulge ? &t.bulge_scores_init[len] : &t.interior_scores_init[len];
-  const float A = *pa, B = *pb, C = *pc;  // three independent loads
-  const float penc = augu(ci, cj) ? t.helix_augu_end_penalty : 0.f;
-  const float peni = augu(ak, al) ? t.helix_augu_end_penalty : 0.f;
-  if (generic) {
-    const uint32_t diff = a > b ? a - b : b - a;
-    const float nin = t.ninio_coeff * static_cast<float>(diff);
-    const float mm = A + B;
-    return C + (nin > t.ninio_max ? nin : t.ninio_max) + mm + penc + peni;
-  }
-  if (bulge1) return C + A;
-  if (bulgeN) return C + penc + peni;
-  return A;
-}
+// (turner_twoloop_flat itself lives in rnamc_scoring.h: the tree-order kernels use it too)
 
 // ----------------------------------------------------------------------------
 // The 2-loop blocks of one listed cell per wave.  The probes (a, b) are taken in fold order

@@ -189,6 +189,97 @@ struct Contra {
   }
 };
 
+
+// ----------------------------------------------------------------------------
+// Flat forms of the 2-loop scores: every table lookup of a call is issued at once (the branchy
+// forms above walk the loop classes one after the other, and lanes of one wave hold different
+// classes).  Arguments are base codes: (ci,cj) closes, (ak,al) is enclosed; x1,x2 = the two
+// bases inside ci, y1,y2 inside cj; m2,m3 = the bases outside al and ak; a, b = unpaired bases
+// on the two sides.  turner_twoloop_flat evaluates the same expression tree per class as
+// Turner::twoloop (bit-identical; the reference-order latency forms rely on that).
+RNAMC_HD float turner_twoloop_flat(const rnamc_turner_scores& t, uint32_t a,
+                                                     uint32_t b, int ci, int cj, int x1, int x2,
+                                                     int y1, int y2, int ak, int al, int m2, int m3) {
+  const bool bulge = (a == 0u) != (b == 0u);
+  const uint32_t len = a + b;
+  const bool stack = len == 0u, bulge1 = bulge && len == 1u, bulgeN = bulge && len > 1u;
+  const bool i11 = a == 1u && b == 1u, i12 = a == 1u && b == 2u, i21 = a == 2u && b == 1u,
+             i22 = a == 2u && b == 2u;
+  const bool generic = !(stack || bulge || i11 || i12 || i21 || i22);
+  // primary entry
+  const float* tmx = (a == 1u || b == 1u) ? &t.terminal_mismatch_scores_1xmany[0][0][0][0]
+                     : ((a == 2u && b == 3u) || (a == 3u && b == 2u))
+                         ? &t.terminal_mismatch_scores_2x3[0][0][0][0]
+                         : &t.terminal_mismatch_scores_interior[0][0][0][0];
+  const float* pa;
+  if (stack || bulge1) {
+    pa = &t.stack_scores[ci][cj][ak][al];
+  } else if (i11) {
+    pa = &t.interior_scores_1x1[ci][cj][x1][y1][ak][al];
+  } else if (i12) {
+    pa = &t.interior_scores_1x2[ci][cj][x1][y1][y2][ak][al];
+  } else if (i21) {
+    pa = &t.interior_scores_1x2[al][ak][y1][x2][x1][cj][ci];
+  } else if (i22) {
+    pa = &t.interior_scores_2x2[ci][cj][x1][y1][x2][y2][ak][al];
+  } else {
+    pa = tmx + ((ci * 4 + cj) * 4 + x1) * 4 + y1;  // (bulgeN: read, not used)
+  }
+  const float* pb = tmx + ((al * 4 + ak) * 4 + m2) * 4 + m3;
+  const float* pc = bulge ? &t.bulge_scores_init[len] : &t.interior_scores_init[len];
+  const float A = *pa, B = *pb, C = *pc;  // three independent loads
+  const float penc = augu(ci, cj) ? t.helix_augu_end_penalty : 0.f;
+  const float peni = augu(ak, al) ? t.helix_augu_end_penalty : 0.f;
+  if (generic) {
+    const uint32_t diff = a > b ? a - b : b - a;
+    const float nin = t.ninio_coeff * static_cast<float>(diff);
+    const float mm = A + B;
+    return C + (nin > t.ninio_max ? nin : t.ninio_max) + mm + penc + peni;
+  }
+  if (bulge1) return C + A;
+  if (bulgeN) return C + penc + peni;
+  return A;
+}
+
+// get_2loop_score_contra (src/utils.rs:423-520) + the enclosed pair's base-pair score
+// (src/mccaskill_algo.rs:441).  Same terms as Contra::twoloop; the association of the sum
+// differs (tree-order mode only: not bit-comparable with the reference anyway).
+RNAMC_HD float contra_twoloop_flat(const rnamc_fold_score_sets& f, uint32_t a, uint32_t b, int ci,
+                                   int cj, int x1, int y1, int ak, int al, int m2, int m3) {
+  const uint32_t len = a + b;
+  const bool stack = len == 0u;
+  const bool bulge = (a == 0u) != (b == 0u);
+  const bool inter = a != 0u && b != 0u;
+  const uint32_t diff = a > b ? a - b : b - a;
+  // all independent loads, indices clamped into their tables
+  const float st = f.stack_scores[ci][cj][ak][al];
+  const float bp = f.basepair_scores[ak][al];
+  const float js0 = f.helix_close_scores[ci][cj] + f.terminal_mismatch_scores[ci][cj][x1][y1];
+  const float js1 = f.helix_close_scores[al][ak] + f.terminal_mismatch_scores[al][ak][m2][m3];
+  const float b01 = f.bulge_scores_0x1[a == 1u ? x1 : y1];
+  const uint32_t lb = len >= 1u ? (len - 1u < RNAMC_MAX_LOOP_LEN ? len - 1u : RNAMC_MAX_LOOP_LEN - 1u) : 0u;
+  const float blen = f.bulge_scores_len_cumulative[lb];
+  const uint32_t li = len >= 2u ? (len - 2u < RNAMC_MAX_LOOP_LEN - 1u ? len - 2u : RNAMC_MAX_LOOP_LEN - 2u) : 0u;
+  const float ilen = f.interior_scores_len_cumulative[li];
+  const float i11 = f.interior_scores_1x1[x1][y1];
+  const uint32_t sa = a >= 1u ? (a - 1u < RNAMC_MAX_INTERIOR_SYMMETRIC ? a - 1u : RNAMC_MAX_INTERIOR_SYMMETRIC - 1u) : 0u;
+  const float sym = f.interior_scores_symmetric_cumulative[sa];
+  const uint32_t da = diff >= 1u ? (diff - 1u < RNAMC_MAX_INTERIOR_ASYMMETRIC ? diff - 1u : RNAMC_MAX_INTERIOR_ASYMMETRIC - 1u) : 0u;
+  const float asym = f.interior_scores_asymmetric_cumulative[da];
+  const bool expl = inter && a <= RNAMC_MAX_INTERIOR_EXPLICIT && b <= RNAMC_MAX_INTERIOR_EXPLICIT;
+  const float ex = f.interior_scores_explicit[expl ? a - 1u : 0u][expl ? b - 1u : 0u];
+  float sc;
+  if (stack) {
+    sc = st;
+  } else if (bulge) {
+    sc = (len == 1u ? b01 : 0.f) + blen + js0 + js1;
+  } else {
+    const float s0 = (a == b) ? ((len == 2u ? i11 : 0.f) + sym) : asym;
+    sc = s0 + (expl ? ex : 0.f) + ilen + js0 + js1;
+  }
+  return sc + bp;
+}
+
 }  // namespace rnamc
 
 #endif

@@ -48,7 +48,6 @@ namespace {
 constexpr float kL2E = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 constexpr float kEmpty = -1.0e30f;  // running max of an accumulator without terms
-constexpr int kThreads = 256;
 
 __device__ __forceinline__ float vmaxf(float a, float b) {
   float r;
@@ -75,6 +74,13 @@ __device__ __forceinline__ void acc_add4(Acc& a, float x0, float x1, float x2, f
   const float e01 = ex2(__builtin_fmaf(x0, kL2E, -mb)) + ex2(__builtin_fmaf(x1, kL2E, -mb));
   const float e23 = ex2(__builtin_fmaf(x2, kL2E, -mb)) + ex2(__builtin_fmaf(x3, kL2E, -mb));
   a.s = __builtin_fmaf(a.s, ex2((a.m - mn) * kL2E), e01 + e23);
+  a.m = mn;
+}
+__device__ __forceinline__ void acc_add2(Acc& a, float x0, float x1) {
+  const float mn = vmaxf(a.m, vmaxf(x0, x1));
+  const float mb = mn * kL2E;
+  const float e01 = ex2(__builtin_fmaf(x0, kL2E, -mb)) + ex2(__builtin_fmaf(x1, kL2E, -mb));
+  a.s = __builtin_fmaf(a.s, ex2((a.m - mn) * kL2E), e01);
   a.m = mn;
 }
 __device__ __forceinline__ void acc_merge(Acc& a, const Acc& b) {
@@ -127,36 +133,41 @@ __device__ __forceinline__ Acc wave_reduce(const Acc& a) {
   return Acc{m, s};
 }
 
-// Workgroup reduction of NA accumulators: every wave reduces its own, lane 0 parks the pair
-// in LDS, and after the barrier every thread merges the four pairs (so that each thread holds
-// the workgroup's totals without a second barrier).
-template <int NA>
-__device__ __forceinline__ void block_reduce(Acc (&a)[NA], float (*lds)[NA][2]) {
-  const uint32_t wave = threadIdx.x >> 6;
+// Reduction of NA accumulators over the TPC threads that share a cell.  TPC == 64: the wave's
+// own DPP reduction, no LDS, no barrier.  Larger groups: every wave parks its pair in LDS,
+// after the barrier the first wave reduces the W = TPC / 64 pairs once more; the other waves
+// are done (returns false for them).
+template <int NA, int TPC>
+__device__ __forceinline__ bool cell_reduce(Acc (&a)[NA], float (*lds)[NA][2]) {
 #pragma unroll
-  for (int x = 0; x < NA; x++) {
-    const Acc r = wave_reduce(a[x]);
-    if ((threadIdx.x & 63u) == 0u) {
-      lds[wave][x][0] = r.m;
-      lds[wave][x][1] = r.s;
+  for (int x = 0; x < NA; x++) a[x] = wave_reduce(a[x]);
+  if (TPC == 64) return true;
+  constexpr int W = TPC / 64;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  if (lane == 0u) {
+#pragma unroll
+    for (int x = 0; x < NA; x++) {
+      lds[wave][x][0] = a[x].m;
+      lds[wave][x][1] = a[x].s;
     }
   }
   __syncthreads();
+  if (wave != 0u) return false;
 #pragma unroll
   for (int x = 0; x < NA; x++) {
-    Acc t = Acc{lds[0][x][0], lds[0][x][1]};
-#pragma unroll
-    for (int w = 1; w < kThreads / 64; w++) acc_merge(t, Acc{lds[w][x][0], lds[w][x][1]});
-    a[x] = t;
+    Acc t = lane < static_cast<uint32_t>(W) ? Acc{lds[lane][x][0], lds[lane][x][1]} : acc_empty();
+    a[x] = wave_reduce(t);
   }
+  return true;
 }
 
-// (+)_k (A[k] + B[k]) over k in [0, len): both operands contiguous in k, the workgroup's
+// (+)_k (A[k] + B[k]) over k in [0, len): both operands contiguous in k, the cell's TPC
 // lanes take consecutive k (256-B wave accesses), four loads of each operand in flight.
+template <int TPC>
 __device__ __forceinline__ void acc_product(Acc& a, const float* __restrict__ A,
-                                            const float* __restrict__ B, uint32_t len) {
-  for (uint32_t k = threadIdx.x; k < len; k += 4u * kThreads) {
-    const uint32_t k1 = k + kThreads, k2 = k + 2u * kThreads, k3 = k + 3u * kThreads;
+                                            const float* __restrict__ B, uint32_t len, uint32_t t) {
+  for (uint32_t k = t; k < len; k += 4u * TPC) {
+    const uint32_t k1 = k + TPC, k2 = k + 2u * TPC, k3 = k + 3u * TPC;
     const float a0 = A[k], b0 = B[k];
     const float a1 = k1 < len ? A[k1] : kNegInf, b1 = k1 < len ? B[k1] : kNegInf;
     const float a2 = k2 < len ? A[k2] : kNegInf, b2 = k2 < len ? B[k2] : kNegInf;
@@ -171,6 +182,7 @@ struct TSeq {
   float* m[T_COUNT];
   float* zp;   // zp[x] = Z(0, x-1), zp[0] = 0            (n + 1 entries)
   float* zs;   // zs[x] = Z(x, n-1), zs[n] = 0            (n + 1 entries)
+  const uint32_t* pk;  // 2-bit packed bases, 16 per word, position p at bit 2(p+32)
   float* out;  // packed diagonal-major triangle: log bpp until k_tree_finalize
   uint32_t batch_idx;
 };
@@ -186,6 +198,7 @@ __device__ __forceinline__ TSeq load_tseq(const TreeBatch& b, uint32_t which) {
   for (int x = 0; x < T_COUNT; x++) q.m[x] = base + static_cast<size_t>(x) * sd.msz;
   q.zp = base + static_cast<size_t>(T_COUNT) * sd.msz;
   q.zs = q.zp + (sd.n + 64u);
+  q.pk = reinterpret_cast<const uint32_t*>(b.workspace + sd.pk_off);
   q.out = b.out + sd.out_off;
   q.batch_idx = sd.batch_idx;
   return q;
@@ -194,6 +207,18 @@ __device__ __forceinline__ TSeq load_tseq(const TreeBatch& b, uint32_t which) {
 __device__ __forceinline__ uint32_t tri_off(uint32_t n, uint32_t d) {
   return d * n - (d * (d - 1u)) / 2u;
 }
+
+// 32 consecutive bases p0 .. p0+31 in one 64-bit value (window position q at bits 2q, 2q+1);
+// p0 >= -32 (the packed copy carries 32 zero bases in front and >= 64 behind)
+__device__ __forceinline__ uint64_t load_win64(const uint32_t* __restrict__ pk, int p0) {
+  const uint32_t bit = 2u * static_cast<uint32_t>(p0 + 32);
+  const uint32_t w = bit >> 5, sh = bit & 31u;
+  const uint32_t w0 = pk[w], w1 = pk[w + 1], w2 = pk[w + 2];
+  const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
+  const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+  return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+__device__ __forceinline__ int wb(uint64_t w, uint32_t q) { return static_cast<int>((w >> (2u * q)) & 3u); }
 
 // The <= 496 (a, b) pairs with a + b <= 30 (src/mccaskill_algo.rs:306-315) in 512 slots: slot
 // row r < 15 holds the 31 - r pairs of a = r followed by the r + 1 pairs of a = 30 - r; row 15
@@ -214,10 +239,20 @@ struct TModel<false> {
   static __device__ __forceinline__ Turner make(const TreeBatch& b) {
     return Turner{b.params->turner, b.hp_init};
   }
+  static __device__ __forceinline__ float twoloop(const TreeBatch& b, uint32_t a, uint32_t bb, int ci,
+                                                  int cj, int x1, int x2, int y1, int y2, int ak,
+                                                  int al, int m2, int m3) {
+    return turner_twoloop_flat(b.params->turner, a, bb, ci, cj, x1, x2, y1, y2, ak, al, m2, m3);
+  }
 };
 template <>
 struct TModel<true> {
   static __device__ __forceinline__ Contra make(const TreeBatch& b) { return Contra{b.params->contra}; }
+  static __device__ __forceinline__ float twoloop(const TreeBatch& b, uint32_t a, uint32_t bb, int ci,
+                                                  int cj, int x1, int /*x2*/, int y1, int /*y2*/,
+                                                  int ak, int al, int m2, int m3) {
+    return contra_twoloop_flat(b.params->contra, a, bb, ci, cj, x1, y1, ak, al, m2, m3);
+  }
 };
 
 // ----------------------------------------------------------------------------
@@ -242,6 +277,17 @@ __global__ void __launch_bounds__(256) k_tree_init(TreeBatch b, int contra, int 
       zp[x] = contra ? unp * static_cast<float>(x) : 0.f;
       zs[x] = contra ? unp * static_cast<float>(sd.n - x) : 0.f;
     }
+    // 2-bit packed copy of the sequence: base p at bit 2(p+32); zeros around it
+    uint32_t* pk = reinterpret_cast<uint32_t*>(b.workspace + sd.pk_off);
+    const uint8_t* s = b.bases + sd.seq_off;
+    for (size_t wd = t0; wd < sd.pk_words; wd += stride) {
+      uint32_t v = 0;
+      for (uint32_t y = 0; y < 16; y++) {
+        const int64_t pos = static_cast<int64_t>(wd) * 16 + y - 32;
+        if (pos >= 0 && pos < static_cast<int64_t>(sd.n)) v |= static_cast<uint32_t>(s[pos] & 3u) << (2u * y);
+      }
+      pk[wd] = v;
+    }
   } else {
     // the four slots the outside sweep reuses (W, R, Pm2, SP)
     const int mats[4] = {T_ZRE, T_ZRM, T_QM, T_U};
@@ -253,114 +299,513 @@ __global__ void __launch_bounds__(256) k_tree_init(TreeBatch b, int contra, int 
 }
 
 // ----------------------------------------------------------------------------
-// inside pass, one workgroup per cell (i, i+d)
+// 2-loop terms.  The <= 496 probes of a cell sit in 512 slots spread over the cell's lanes.  A
+// generic loop costs a table lookup: length part of the slot + the fixed pair's side (uniform
+// over the cell, by class) + the varying pair's side from a 256-entry table indexed by the four
+// bases around that pair, which are adjacent 2-bit fields of the two base windows.  The few
+// small loops with explicit tables (Turner: stack, 0x1, 1x1, 1x2, 2x1, 2x2; CONTRAfold: stack,
+// 0x1, 1x1) are scored by the flat scorers of rnamc_scoring.h in one extra pass of the cell's
+// first lanes.
 template <bool CONTRA>
-__global__ void __launch_bounds__(256) k_tree_inside(TreeBatch b, uint32_t d) {
-  __shared__ float red[kThreads / 64][4][2];
+struct Special;
+template <>
+struct Special<false> {
+  static constexpr uint32_t N = 7;
+  static __device__ __forceinline__ void slot(uint32_t t, uint32_t& a, uint32_t& bb) {
+    // (0,0) (0,1) (1,0) (1,1) (1,2) (2,1) (2,2)
+    a = t < 2u ? 0u : (t < 5u ? 1u : 2u);
+    bb = t == 0u ? 0u : (t == 1u ? 1u : (t == 2u ? 0u : (t == 3u ? 1u : (t == 4u ? 2u : (t == 5u ? 1u : 2u)))));
+  }
+};
+template <>
+struct Special<true> {
+  static constexpr uint32_t N = 4;
+  static __device__ __forceinline__ void slot(uint32_t t, uint32_t& a, uint32_t& bb) {
+    // (0,0) (0,1) (1,0) (1,1)
+    a = t >> 1;
+    bb = t & 1u;
+  }
+};
+
+__device__ __forceinline__ float sel4(uint32_t c, float v0, float v1, float v2, float v3) {
+  return c == 0u ? v0 : (c == 1u ? v1 : (c == 2u ? v2 : v3));
+}
+
+// side of a FIXED pair (p0,p1) with the two bases q0 next to p0 and q1 next to p1 on the loop
+// side, per class: Turner pen | mismatch_c[p0][p1][q0][q1] + pen; CONTRAfold helix_close +
+// terminal_mismatch (+ extra: the base-pair score when the pair is the enclosed one)
+template <bool CONTRA>
+__device__ __forceinline__ void fixed_side(const TreeBatch& b, int p0, int p1, int q0, int q1, float extra,
+                                           float (&v)[4]) {
+  if (CONTRA) {
+    const rnamc_fold_score_sets& f = b.params->contra;
+    const float x = (f.helix_close_scores[p0][p1] + f.terminal_mismatch_scores[p0][p1][q0][q1]) + extra;
+    v[0] = v[1] = v[2] = v[3] = x;
+  } else {
+    const rnamc_turner_scores& tt = b.params->turner;
+    const float pen = augu(p0, p1) ? tt.helix_augu_end_penalty : 0.f;
+    v[0] = pen;
+    v[1] = tt.terminal_mismatch_scores_1xmany[p0][p1][q0][q1] + pen;
+    v[2] = tt.terminal_mismatch_scores_2x3[p0][p1][q0][q1] + pen;
+    v[3] = tt.terminal_mismatch_scores_interior[p0][p1][q0][q1] + pen;
+  }
+}
+
+// closing-pair block of cell (i,j): hairpin and multibranch term (both held by the caller,
+// uniform) and the <= 496 enclosed pairs (src/mccaskill_algo.rs:306-325 / 412-436);
+// wi = bases i .. i+31, wj = bases j-31 .. j
+template <bool CONTRA, int TPC>
+__device__ __forceinline__ void pair_block(const TreeBatch& b, const float* __restrict__ qb_r,
+                                           uint32_t ld, Acc& acc, uint32_t i, uint32_t j, uint32_t t,
+                                           uint64_t wi, uint64_t wj, float hp, float mbt) {
+  const uint32_t d = j - i;
+  acc_add(acc, t == 0u ? hp : (t == 1u ? mbt : kNegInf));
+#ifdef RNAMC_DEBUG_KNOBS
+  if (b.debug & 1) return;
+#endif
+  if (d < 3u) return;
+  const int ci = wb(wi, 0), cj = wb(wj, 31);
+  const int x1 = wb(wi, 1), x2 = wb(wi, 2), y1 = wb(wj, 30), y2 = wb(wj, 29);
+  float cs[4];
+  fixed_side<CONTRA>(b, ci, cj, x1, y1, 0.f, cs);
+  const float* __restrict__ tin = &b.tabs->in[CONTRA ? 1 : 0][0][0];
+  const float* __restrict__ tlen = &b.tabs->len[CONTRA ? 1 : 0][0];
+  const uint32_t* __restrict__ tslot = &b.tabs->slot[CONTRA ? 1 : 0][0];
+#pragma unroll
+  for (uint32_t p = t; p < 512u; p += TPC) {
+    const uint32_t sl = tslot[p];
+    const float ln = tlen[p];
+    const uint32_t a = sl & 255u, bb = (sl >> 8) & 255u, cls = (sl >> 16) & 255u;
+    if ((sl >> 24) == 1u && a + bb + 3u <= d) {
+      const uint32_t k = i + 1u + a, l = j - 1u - bb;
+      const float x = qb_r[static_cast<size_t>(k) * ld + l];
+      const uint32_t idx = (static_cast<uint32_t>(wi >> (2u * a)) & 15u) |
+                           ((static_cast<uint32_t>(wj >> (60u - 2u * bb)) & 15u) << 4);
+      const float sc = (ln + sel4(cls, cs[0], cs[1], cs[2], cs[3])) + tin[cls * 256u + idx];
+      acc_add(acc, x + sc);  // (absent pair: x = -inf)
+    }
+  }
+  if (t < Special<CONTRA>::N) {
+    uint32_t a, bb;
+    Special<CONTRA>::slot(t, a, bb);
+    if (a + bb + 3u <= d) {
+      const uint32_t k = i + 1u + a, l = j - 1u - bb;
+      const float x = qb_r[static_cast<size_t>(k) * ld + l];
+      // (k,l) = bases at window positions 1+a / 30-bb; their outer neighbours a / 31-bb
+      const float sc = TModel<CONTRA>::twoloop(b, a, bb, ci, cj, x1, x2, y1, y2, wb(wi, 1u + a),
+                                               wb(wj, 30u - bb), wb(wj, 31u - bb), wb(wi, a));
+      acc_add(acc, x + sc);
+    }
+  }
+}
+
+// enclosing 2-loops of the finished pair (i,j) (574-593 / 681-700): (k,l) = (i-1-a, j+1+b)
+// closes, (i,j) is enclosed; operands {log bpp, sums_close}(k,l) in one 8-byte load
+template <bool CONTRA, int TPC>
+__device__ __forceinline__ void outer_block(const TreeBatch& b, const TSeq& q, Acc& acc, uint32_t i,
+                                            uint32_t j, uint32_t t, float qb) {
+#ifdef RNAMC_DEBUG_KNOBS
+  if (b.debug & 1) return;
+#endif
+  const uint32_t n = q.n, ld = q.ld;
+  const float2* __restrict__ pq_r = reinterpret_cast<const float2*>(q.m[T_PQ]);
+  // bases i-31 .. i and j .. j+31
+  const uint64_t wi = load_win64(q.pk, static_cast<int>(i) - 31);
+  const uint64_t wj = load_win64(q.pk, static_cast<int>(j));
+  const int ai = wb(wi, 31), aj = wb(wj, 0), m3 = wb(wi, 30), m2 = wb(wj, 1);
+  float es[4];
+  fixed_side<CONTRA>(b, aj, ai, m2, m3, CONTRA ? b.params->contra.basepair_scores[ai][aj] : 0.f, es);
+  const float* __restrict__ tout = &b.tabs->out[CONTRA ? 1 : 0][0][0];
+  const float* __restrict__ tlen = &b.tabs->len[CONTRA ? 1 : 0][0];
+  const uint32_t* __restrict__ tslot = &b.tabs->slot[CONTRA ? 1 : 0][0];
+#pragma unroll
+  for (uint32_t p = t; p < 512u; p += TPC) {
+    const uint32_t sl = tslot[p];
+    const float ln = tlen[p];
+    const uint32_t a = sl & 255u, bb = (sl >> 8) & 255u, cls = (sl >> 16) & 255u;
+    if ((sl >> 24) == 1u && a < i && j + 1u + bb < n) {
+      const uint32_t k = i - 1u - a, l = j + 1u + bb;
+      const float2 pq = pq_r[static_cast<size_t>(k) * ld + l];
+      const uint32_t idx = (static_cast<uint32_t>(wi >> (60u - 2u * a)) & 15u) |
+                           ((static_cast<uint32_t>(wj >> (2u * bb)) & 15u) << 4);
+      const float sc = (ln + sel4(cls, es[0], es[1], es[2], es[3])) + tout[cls * 256u + idx];
+      if (pq.y > kNegInf) acc_add(acc, ((pq.x + qb) - pq.y) + sc);
+    }
+  }
+  if (t < Special<CONTRA>::N) {
+    uint32_t a, bb;
+    Special<CONTRA>::slot(t, a, bb);
+    if (a < i && j + 1u + bb < n) {
+      const uint32_t k = i - 1u - a, l = j + 1u + bb;
+      const float2 pq = pq_r[static_cast<size_t>(k) * ld + l];
+      // closing pair at window positions 30-a / 1+bb; its inner neighbours 31-a, 32-a / bb, bb-1
+      const float sc = TModel<CONTRA>::twoloop(b, a, bb, wb(wi, 30u - a), wb(wj, 1u + bb), wb(wi, 31u - a),
+                                               wb(wi, a >= 1u ? 32u - a : 31u), wb(wj, bb),
+                                               wb(wj, bb >= 1u ? bb - 1u : 0u), ai, aj, m2, m3);
+      if (pq.y > kNegInf) acc_add(acc, ((pq.x + qb) - pq.y) + sc);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------
+// inside pass.  TPC threads share the cell (i, i+d): 64 (four cells per workgroup, no
+// barrier), 256 or 1024 (one cell per workgroup); the host picks by how many cells the
+// diagonal holds.  Scalars of the cell are computed by all of its threads alike (uniform
+// loads issued at the top, beside the operand streams); its first lane stores.
+template <bool CONTRA, int TPC>
+__global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside(TreeBatch b, uint32_t d) {
+  constexpr int BLOCK = TPC < 256 ? 256 : TPC;
+  __shared__ float red[BLOCK / 64][4][2];
+#ifdef RNAMC_DEBUG_KNOBS
+  if (b.debug & 4) return;
+#endif
   const TSeq q = load_tseq(b, blockIdx.y);
   const uint32_t n = q.n, ld = q.ld;
-  const uint32_t i = blockIdx.x;
+  // (wave-uniform: TPC is a multiple of 64; readfirstlane lets the cell's scalar work run on
+  // the scalar unit)
+  const uint32_t i = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
+      static_cast<int>(blockIdx.x * (BLOCK / TPC) + threadIdx.x / TPC)));
   if (i + d >= n) return;
   const uint32_t j = i + d;
-  const uint32_t t = threadIdx.x;
+  const uint32_t t = threadIdx.x % TPC;
   const uint8_t* __restrict__ s = q.s;
   const auto model = TModel<CONTRA>::make(b);
   const float* __restrict__ qb_r = q.m[T_QB];
   const size_t row_i = static_cast<size_t>(i) * ld, col_j = static_cast<size_t>(j) * ld;
+  // bases i .. i+31 and j-31 .. j
+  const uint64_t wi = load_win64(q.pk, static_cast<int>(i));
+  const uint64_t wj = load_win64(q.pk, static_cast<int>(j) - 31);
+  const int ci = wb(wi, 0), cj = wb(wj, 31);
 
-  bool act = canonical(s[i], s[j]);
+  bool act = canonical(ci, cj);
   if (!(b.allows_short_hairpins && CONTRA) && d + 1 < RNAMC_MIN_SPAN_HAIRPIN_CLOSE) act = false;
 
-  // thread 0 owns the cell's scalar recurrences: fetch their operands first
-  float zr_e_prev = kNegInf, zr_m_prev = kNegInf, u_next = kNegInf;
-  if (t == 0) {
-    if (j >= 1) {
-      zr_e_prev = q.m[T_ZRE][col_j - ld + i];
-      if (CONTRA) zr_m_prev = q.m[T_ZRM][col_j - ld + i];
-    }
-    u_next = q.m[T_U][col_j + i + 1];  // (i+1 == n: the column's pad, -inf)
+  // operands of the cell's scalar recurrences (uniform loads)
+  float zr_e_prev = kNegInf, zr_m_prev = kNegInf;
+  if (j >= 1) {
+    zr_e_prev = q.m[T_ZRE][col_j - ld + i];
+    if (CONTRA) zr_m_prev = q.m[T_ZRM][col_j - ld + i];
+  }
+  const float u_next = q.m[T_U][col_j + i + 1];  // (i+1 == n: the column's pad, -inf)
+  const float zs_next = (j == n - 1) ? q.zs[i + 1] : 0.f;
+  float hp = kNegInf, mbt = kNegInf, accs = 0.f;
+  if (act) {
+    if (!CONTRA || d - 1 <= RNAMC_MAX_LOOP_LEN) hp = model.hairpin(s, n, i, j);
+    if (d >= 2) mbt = q.m[T_QM][row_i + ld + (j - 1)] + model.mbclose(s, n, i, j);
+    accs = model.accessible(s, n, i, j);
   }
 
   Acc acc[4] = {acc_empty(), acc_empty(), acc_empty(), acc_empty()};
   // [0] closing-pair block (297-343 / 400-467)
-  if (act) {
-    if (t == 0 && (!CONTRA || d - 1 <= RNAMC_MAX_LOOP_LEN)) acc_add(acc[0], model.hairpin(s, n, i, j));
-    if (t == 1 && d >= 2)
-      acc_add(acc[0], q.m[T_QM][row_i + ld + (j - 1)] + model.mbclose(s, n, i, j));
-    if (d >= 3) {
-#pragma unroll
-      for (uint32_t p = t; p < 512u; p += kThreads) {
-        uint32_t a, bb;
-        if (probe_slot(p, a, bb) && a + bb + 3u <= d) {
-          const uint32_t k = i + 1u + a, l = j - 1u - bb;
-          const float x = qb_r[static_cast<size_t>(k) * ld + l];
-          if (x > kNegInf) acc_add(acc[0], x + model.twoloop(s, i, j, k, l));
-        }
-      }
-    }
-  }
+  if (act) pair_block<CONTRA, TPC>(b, qb_r, ld, acc[0], i, j, t, wi, wj, hp, mbt);
   // [1] sums_multibranch (L_c second fold): k = i+1 .. j-1, Q1(i,k-1) + Zr_mb(k,j)
-  if (d >= 2) acc_product(acc[1], q.m[T_Q1R] + row_i + i, q.m[T_ZRM] + col_j + i + 1, d - 1);
+#ifdef RNAMC_DEBUG_KNOBS
+  if (!(b.debug & 2))
+#endif
+  if (d >= 2) acc_product<TPC>(acc[1], q.m[T_Q1R] + row_i + i, q.m[T_ZRM] + col_j + i + 1, d - 1, t);
   // [2] Z(0,j): k = 1 .. j, Zr_ext(k,j) + Z(0,k-1)       (the k = 0 term is this cell's own)
-  if (i == 0 && j >= 1) acc_product(acc[2], q.m[T_ZRE] + col_j + 1, q.zp + 1, j);
+  if (i == 0 && j >= 1) acc_product<TPC>(acc[2], q.m[T_ZRE] + col_j + 1, q.zp + 1, j, t);
   // [3] Z(i,n-1): l = i+1 .. n-2, Qa(i,l) + Z(l+1,n-1)   (l = n-1 is this cell's own)
-  if (j == n - 1 && d >= 1) acc_product(acc[3], q.m[T_QA] + row_i + i + 1, q.zs + i + 2, d - 1);
-  block_reduce<4>(acc, red);
-  if (t != 0) return;
+  if (j == n - 1 && d >= 1) acc_product<TPC>(acc[3], q.m[T_QA] + row_i + i + 1, q.zs + i + 2, d - 1, t);
+  if (!cell_reduce<4, TPC>(acc, red)) return;
 
   const float ext_bp = CONTRA ? b.params->contra.external_score_basepair : 0.f;
   const float ext_un = CONTRA ? b.params->contra.external_score_unpair : 0.f;
   const float mb_bp = CONTRA ? b.params->contra.multibranch_score_basepair
                              : b.params->turner.coeff_num_branches;
   const float mb_un = CONTRA ? b.params->contra.multibranch_score_unpair : 0.f;
+  const bool st = t == 0u;  // the lane that stores
   float qa = kNegInf;
   if (act) {
     const float qb = acc_value(acc[0]);
     if (qb > kNegInf) {
-      qa = qb + model.accessible(s, n, i, j);
-      q.m[T_QB][row_i + j] = qb;
-      q.m[T_QA][row_i + j] = qa;
+      qa = qb + accs;
+      if (st) {
+        q.m[T_QB][row_i + j] = qb;
+        q.m[T_QA][row_i + j] = qa;
+      }
     }
   }
   // sums_rightmost_basepairs_{external,multibranch}: one step from the cell to the left
   const float zr_e = lse2(zr_e_prev + ext_un, qa + ext_bp);
   const float zr_m = CONTRA ? lse2(zr_m_prev + mb_un, qa + mb_bp) : zr_e + mb_bp;
-  q.m[T_ZRE][col_j + i] = zr_e;
-  q.m[T_ZRM][col_j + i] = zr_m;
   const float u = lse2(u_next + mb_un, zr_m);
-  q.m[T_U][col_j + i] = u;
   const float qm = acc_value(acc[1]);
-  q.m[T_QM][row_i + j] = qm;
   const float q1 = lse2(u, qm);
-  q.m[T_Q1R][row_i + j] = q1;
-  q.m[T_Q1C][col_j + i] = q1;
+  if (st) {
+    q.m[T_ZRE][col_j + i] = zr_e;
+    q.m[T_ZRM][col_j + i] = zr_m;
+    q.m[T_U][col_j + i] = u;
+    q.m[T_QM][row_i + j] = qm;
+    q.m[T_Q1R][row_i + j] = q1;
+    q.m[T_Q1C][col_j + i] = q1;
+  }
   if (i == 0) {
     // sums_external[0][j] (352-363 / 487-498)
     Acc z = acc[2];
     acc_add(z, zr_e);  // k = 0: Z(0,-1) = 0
     acc_add(z, CONTRA ? ext_un * static_cast<float>(j + 1) : 0.f);
-    q.zp[j + 1] = acc_value(z);
+    if (st) q.zp[j + 1] = acc_value(z);
   }
   if (j == n - 1) {
     Acc z = acc[3];
     z.m += ext_bp;            // every product term carries the pair's external_score_basepair
     acc_add(z, qa + ext_bp);  // l = n-1: Z(n,n-1) = 0
-    acc_add(z, q.zs[i + 1] + ext_un);
-    q.zs[i] = acc_value(z);
+    acc_add(z, zs_next + ext_un);
+    if (st) q.zs[i] = acc_value(z);
   }
 }
 
 // ----------------------------------------------------------------------------
-// outside pass, one workgroup per cell (i, i+d)
-template <bool CONTRA>
-__global__ void __launch_bounds__(256) k_tree_outside(TreeBatch b, uint32_t d) {
-  __shared__ float red[kThreads / 64][3][2];
+// Two diagonals per launch.  The sweep's cost is its NUMBER of dependent launches (each a
+// few microseconds of launch gap, operand round trips and drain), so one workgroup takes the
+// cells (i, j) and (i, j+1) of diagonals d and d+1.  What diagonal d+1 needs of diagonal d:
+//   inside : Zr(i,j) (own cell) and U(i+1,j+1), one step from U(i+2,j+1) given the
+//            closing-pair block of the neighbour (i+1,j+1), which is evaluated a second time here
+//            (sums_multibranch(i,j+1) itself does not: its k = i+1 term carries Q1(i,i) = -inf);
+//   outside: W(i,j+1), Pm2(i,j+1) (own cell) and probs_multibranch(i-1,j) for the column
+//            prefix, a product that shares its Q1 row with the cell's own and is evaluated here
+//            as a third stream (the k = j+1 term of Pm(i,j) carries Q1(j+1,j) = -inf, and the
+//            k = i-1 term of L_e Q1(i,i-1) = -inf: neither needs the neighbour).
+
+// (+)_k over idx in [0, len1): a = A[idx]; acc0 += a + B0[idx] (idx < len0); acc1 += a + B1[idx]
+template <int TPC>
+__device__ __forceinline__ void acc_product_2b(Acc& acc0, Acc& acc1, const float* __restrict__ A,
+                                               const float* __restrict__ B0,
+                                               const float* __restrict__ B1, uint32_t len0,
+                                               uint32_t len1, uint32_t t) {
+  for (uint32_t k = t; k < len1; k += 2u * TPC) {
+    const uint32_t k1 = k + TPC;
+    const bool v1 = k1 < len1;
+    const float a0 = A[k], a1 = v1 ? A[k1] : kNegInf;
+    const float p0 = k < len0 ? B0[k] : kNegInf, p1 = k1 < len0 ? B0[k1] : kNegInf;
+    const float r0 = B1[k], r1 = v1 ? B1[k1] : kNegInf;
+    acc_add2(acc0, a0 + p0, a1 + p1);
+    acc_add2(acc1, a0 + r0, a1 + r1);
+  }
+}
+
+template <bool CONTRA, int TPC>
+__global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatch b, uint32_t d) {
+  constexpr int BLOCK = TPC < 256 ? 256 : TPC;
+  constexpr int NA = 9;
+  __shared__ float red[BLOCK / 64][NA][2];
+#ifdef RNAMC_DEBUG_KNOBS
+  if (b.debug & 4) return;
+#endif
   const TSeq q = load_tseq(b, blockIdx.y);
   const uint32_t n = q.n, ld = q.ld;
-  const uint32_t i = blockIdx.x;
+  const uint32_t i = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
+      static_cast<int>(blockIdx.x * (BLOCK / TPC) + threadIdx.x / TPC)));
+  if (i + d >= n) return;
+  const uint32_t j = i + d, j1 = j + 1u;
+  const bool has1 = j1 < n;  // cells (i, j+1) and (i+1, j+1) exist
+  const uint32_t t = threadIdx.x % TPC;
+  const uint8_t* __restrict__ s = q.s;
+  const auto model = TModel<CONTRA>::make(b);
+  const float* __restrict__ qb_r = q.m[T_QB];
+  const size_t row_i = static_cast<size_t>(i) * ld, col_j = static_cast<size_t>(j) * ld;
+  const uint64_t wi = load_win64(q.pk, static_cast<int>(i));          // bases i .. i+31
+  const uint64_t wi1 = load_win64(q.pk, static_cast<int>(i) + 1);     // bases i+1 .. i+32
+  const uint64_t wj = load_win64(q.pk, static_cast<int>(j) - 31);     // bases j-31 .. j
+  const uint64_t wj1 = load_win64(q.pk, static_cast<int>(j) - 30);    // bases j-30 .. j+1
+  const bool span_ok = (b.allows_short_hairpins && CONTRA);
+  const bool act0 = canonical(wb(wi, 0), wb(wj, 31)) && (span_ok || d + 1 >= RNAMC_MIN_SPAN_HAIRPIN_CLOSE);
+  const bool act1 = has1 && canonical(wb(wi, 0), wb(wj1, 31)) && (span_ok || d + 2 >= RNAMC_MIN_SPAN_HAIRPIN_CLOSE);
+  const bool actn = has1 && canonical(wb(wi1, 0), wb(wj1, 31)) && (span_ok || d + 1 >= RNAMC_MIN_SPAN_HAIRPIN_CLOSE);
+
+  // operands of the scalar recurrences (uniform loads, all from diagonals < d)
+  float zr_e_prev = kNegInf, zr_m_prev = kNegInf, zr_e_prevn = kNegInf, zr_m_prevn = kNegInf;
+  if (j >= 1) {
+    zr_e_prev = q.m[T_ZRE][col_j - ld + i];
+    if (CONTRA) zr_m_prev = q.m[T_ZRM][col_j - ld + i];
+  }
+  const float u_next0 = q.m[T_U][col_j + i + 1];            // U(i+1, j)
+  float u_nextn = kNegInf;                                   // U(i+2, j+1)
+  if (has1) {
+    zr_e_prevn = q.m[T_ZRE][col_j + i + 1];                  // Zr_ext(i+1, j)
+    if (CONTRA) zr_m_prevn = q.m[T_ZRM][col_j + i + 1];
+    u_nextn = q.m[T_U][col_j + ld + i + 2];
+  }
+  float hp0 = kNegInf, mbt0 = kNegInf, accs0 = 0.f, hp1 = kNegInf, mbt1 = kNegInf, accs1 = 0.f,
+        hpn = kNegInf, mbtn = kNegInf, accsn = 0.f;
+  if (act0) {
+    if (!CONTRA || d - 1 <= RNAMC_MAX_LOOP_LEN) hp0 = model.hairpin(s, n, i, j);
+    if (d >= 2) mbt0 = q.m[T_QM][row_i + ld + (j - 1)] + model.mbclose(s, n, i, j);
+    accs0 = model.accessible(s, n, i, j);
+  }
+  if (act1) {
+    if (!CONTRA || d <= RNAMC_MAX_LOOP_LEN) hp1 = model.hairpin(s, n, i, j1);
+    if (d >= 1) mbt1 = q.m[T_QM][row_i + ld + j] + model.mbclose(s, n, i, j1);
+    accs1 = model.accessible(s, n, i, j1);
+  }
+  if (actn) {
+    if (!CONTRA || d - 1 <= RNAMC_MAX_LOOP_LEN) hpn = model.hairpin(s, n, i + 1, j1);
+    if (d >= 2) mbtn = q.m[T_QM][row_i + 2 * static_cast<size_t>(ld) + j] + model.mbclose(s, n, i + 1, j1);
+    accsn = model.accessible(s, n, i + 1, j1);
+  }
+  const bool zs0 = j == n - 1, zs1 = has1 && j1 == n - 1;  // which cell sits in column n-1
+  const float zs_a = zs0 ? q.zs[i + 1] : (zs1 ? q.zs[i + 2] : 0.f);  // Z(i+1,n-1) | Z(i+2,n-1)
+
+  Acc acc[NA];
+#pragma unroll
+  for (int x = 0; x < NA; x++) acc[x] = acc_empty();
+  // [0] [1] [2] closing-pair blocks of (i,j), (i+1,j+1), (i,j+1)
+  if (act0) pair_block<CONTRA, TPC>(b, qb_r, ld, acc[0], i, j, t, wi, wj, hp0, mbt0);
+  if (actn) pair_block<CONTRA, TPC>(b, qb_r, ld, acc[1], i + 1, j1, t, wi1, wj1, hpn, mbtn);
+  if (act1) pair_block<CONTRA, TPC>(b, qb_r, ld, acc[2], i, j1, t, wi, wj1, hp1, mbt1);
+  // [3] [4] sums_multibranch of (i,j) and (i,j+1): k = i+1 .. j-1 | j, Q1(i,k-1) + Zr_mb(k,j | j+1)
+  // (the k = i+1 term of the second reads a cell of this launch: masked, it carries Q1(i,i) = -inf)
+#ifdef RNAMC_DEBUG_KNOBS
+  if (!(b.debug & 2))
+#endif
+  {
+    if (has1) {
+      if (d >= 2)
+        acc_product_2b<TPC>(acc[3], acc[4], q.m[T_Q1R] + row_i + i + 1, q.m[T_ZRM] + col_j + i + 2,
+                            q.m[T_ZRM] + col_j + ld + i + 2, d - 2, d - 1, t);
+      // (k = i+1 of the first, left out above to keep both streams on the same k: one lane)
+      if (d >= 2 && t == 0u) acc_add(acc[3], q.m[T_Q1R][row_i + i] + q.m[T_ZRM][col_j + i + 1]);
+    } else if (d >= 2) {
+      acc_product<TPC>(acc[3], q.m[T_Q1R] + row_i + i, q.m[T_ZRM] + col_j + i + 1, d - 1, t);
+    }
+    // [5] [6] Z(0,j), Z(0,j+1): k >= 1 | 2, Zr_ext(k,.) + Z(0,k-1)
+    if (i == 0) {
+      if (j >= 1) acc_product<TPC>(acc[5], q.m[T_ZRE] + col_j + 1, q.zp + 1, j, t);
+      if (has1 && j1 >= 2) acc_product<TPC>(acc[6], q.m[T_ZRE] + col_j + ld + 2, q.zp + 2, j1 - 1, t);
+    }
+    // [7] column n-1 cell of this workgroup: l = i+1 .. n-2, Qa(i,l) + Z(l+1,n-1)
+    //     (zs0: (i,j), all l from memory; zs1: (i,j+1), l = j = n-2 is this workgroup's own cell)
+    if (zs0 && d >= 1) acc_product<TPC>(acc[7], q.m[T_QA] + row_i + i + 1, q.zs + i + 2, d - 1, t);
+    if (zs1 && d >= 1) acc_product<TPC>(acc[7], q.m[T_QA] + row_i + i + 1, q.zs + i + 2, d - 1, t);
+    // [8] zs1: the neighbour (i+1,n-1)'s own sum, l = i+2 .. n-2
+    if (zs1 && d >= 1)
+      acc_product<TPC>(acc[8], q.m[T_QA] + row_i + ld + i + 2, q.zs + i + 3, d - 1, t);
+  }
+  if (!cell_reduce<NA, TPC>(acc, red)) return;
+
+  const float ext_bp = CONTRA ? b.params->contra.external_score_basepair : 0.f;
+  const float ext_un = CONTRA ? b.params->contra.external_score_unpair : 0.f;
+  const float mb_bp = CONTRA ? b.params->contra.multibranch_score_basepair
+                             : b.params->turner.coeff_num_branches;
+  const float mb_un = CONTRA ? b.params->contra.multibranch_score_unpair : 0.f;
+  const bool st = t == 0u;  // the lane that stores
+  // ---- cell (i,j)
+  float qa0 = kNegInf;
+  if (act0) {
+    const float qb = acc_value(acc[0]);
+    if (qb > kNegInf) {
+      qa0 = qb + accs0;
+      if (st) {
+        q.m[T_QB][row_i + j] = qb;
+        q.m[T_QA][row_i + j] = qa0;
+      }
+    }
+  }
+  const float zr_e0 = lse2(zr_e_prev + ext_un, qa0 + ext_bp);
+  const float zr_m0 = CONTRA ? lse2(zr_m_prev + mb_un, qa0 + mb_bp) : zr_e0 + mb_bp;
+  const float u0 = lse2(u_next0 + mb_un, zr_m0);
+  const float qm0 = acc_value(acc[3]);
+  const float q1_0 = lse2(u0, qm0);
+  if (st) {
+    q.m[T_ZRE][col_j + i] = zr_e0;
+    q.m[T_ZRM][col_j + i] = zr_m0;
+    q.m[T_U][col_j + i] = u0;
+    q.m[T_QM][row_i + j] = qm0;
+    q.m[T_Q1R][row_i + j] = q1_0;
+    q.m[T_Q1C][col_j + i] = q1_0;
+  }
+  float zp_j = 0.f;  // Z(0,j)
+  if (i == 0) {
+    Acc z = acc[5];
+    acc_add(z, zr_e0);  // k = 0: Z(0,-1) = 0
+    acc_add(z, CONTRA ? ext_un * static_cast<float>(j + 1) : 0.f);
+    zp_j = acc_value(z);
+    if (st) q.zp[j + 1] = zp_j;
+  }
+  if (zs0) {
+    Acc z = acc[7];
+    z.m += ext_bp;             // every product term carries the pair's external_score_basepair
+    acc_add(z, qa0 + ext_bp);  // l = n-1: Z(n,n-1) = 0
+    acc_add(z, zs_a + ext_un);
+    if (st) q.zs[i] = acc_value(z);
+  }
+  if (!has1) return;
+  // ---- neighbour (i+1,j+1): closing pair -> Zr -> U, not stored (its own workgroup does)
+  float qan = kNegInf;
+  if (actn) {
+    const float qb = acc_value(acc[1]);
+    if (qb > kNegInf) qan = qb + accsn;
+  }
+  const float zr_en = lse2(zr_e_prevn + ext_un, qan + ext_bp);
+  const float zr_mn = CONTRA ? lse2(zr_m_prevn + mb_un, qan + mb_bp) : zr_en + mb_bp;
+  const float un = lse2(u_nextn + mb_un, zr_mn);  // U(i+1, j+1)
+  // ---- cell (i,j+1)
+  const size_t col_j1 = col_j + ld;
+  float qa1 = kNegInf;
+  if (act1) {
+    const float qb = acc_value(acc[2]);
+    if (qb > kNegInf) {
+      qa1 = qb + accs1;
+      if (st) {
+        q.m[T_QB][row_i + j1] = qb;
+        q.m[T_QA][row_i + j1] = qa1;
+      }
+    }
+  }
+  const float zr_e1 = lse2(zr_e0 + ext_un, qa1 + ext_bp);
+  const float zr_m1 = CONTRA ? lse2(zr_m0 + mb_un, qa1 + mb_bp) : zr_e1 + mb_bp;
+  const float u1 = lse2(un + mb_un, zr_m1);
+  const float qm1 = acc_value(acc[4]);
+  const float q1_1 = lse2(u1, qm1);
+  if (st) {
+    q.m[T_ZRE][col_j1 + i] = zr_e1;
+    q.m[T_ZRM][col_j1 + i] = zr_m1;
+    q.m[T_U][col_j1 + i] = u1;
+    q.m[T_QM][row_i + j1] = qm1;
+    q.m[T_Q1R][row_i + j1] = q1_1;
+    q.m[T_Q1C][col_j1 + i] = q1_1;
+  }
+  if (i == 0) {
+    Acc z = acc[6];
+    acc_add(z, zr_e1);                // k = 0
+    acc_add(z, zr_en + q.zp[1]);      // k = 1: Zr_ext(1,j+1) + Z(0,0)
+    acc_add(z, CONTRA ? ext_un * static_cast<float>(j1 + 1) : 0.f);
+    if (st) q.zp[j1 + 1] = acc_value(z);
+  }
+  if (zs1) {
+    // Z(i+1,n-1) of the neighbour first: its own cell term, its memory terms, Z(i+2,n-1)
+    Acc zn = acc[8];
+    zn.m += ext_bp;
+    acc_add(zn, qan + ext_bp);
+    acc_add(zn, zs_a + ext_un);
+    const float zs_n = acc_value(zn);
+    // acc[7] holds the memory terms l = i+1 .. j-1; l = j = n-2 is this launch's own cell (i,j)
+    Acc z = acc[7];
+    z.m += ext_bp;
+    acc_add(z, (qa0 + ext_bp) + q.zs[j + 1]);  // l = j = n-2: Z(n-1,n-1)
+    acc_add(z, qa1 + ext_bp);                  // l = n-1
+    acc_add(z, zs_n + ext_un);
+    if (st) q.zs[i] = acc_value(z);
+  }
+}
+
+// ----------------------------------------------------------------------------
+// outside pass, same thread layout
+template <bool CONTRA, int TPC>
+__global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside(TreeBatch b, uint32_t d) {
+  constexpr int BLOCK = TPC < 256 ? 256 : TPC;
+  __shared__ float red[BLOCK / 64][3][2];
+#ifdef RNAMC_DEBUG_KNOBS
+  if (b.debug & 4) return;
+#endif
+  const TSeq q = load_tseq(b, blockIdx.y);
+  const uint32_t n = q.n, ld = q.ld;
+  const uint32_t i = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
+      static_cast<int>(blockIdx.x * (BLOCK / TPC) + threadIdx.x / TPC)));
   if (i + d >= n) return;
   const uint32_t j = i + d;
-  const uint32_t t = threadIdx.x;
+  const uint32_t t = threadIdx.x % TPC;
   const uint8_t* __restrict__ s = q.s;
   const auto model = TModel<CONTRA>::make(b);
   const float* __restrict__ qb_r = q.m[T_QB];
@@ -371,51 +816,53 @@ __global__ void __launch_bounds__(256) k_tree_outside(TreeBatch b, uint32_t d) {
   float* __restrict__ sp_c = q.m[T_U];          // sp_c(i,j) = (+)_{k<=i} Pm(k,j) [+ unpaired], column-major
 
   const float qb = qb_r[row_i + j];
-  const bool paired = qb > kNegInf;  // (uniform over the workgroup)
+  const bool paired = qb > kNegInf;  // (uniform over the cell's threads)
   float pm2_next = kNegInf, w_next = kNegInf, sp_prev = kNegInf;
-  if (t == 0) {
-    if (j + 1 < n) {
-      pm2_next = pm2_r[row_i + j + 1];
-      w_next = w_r[row_i + j + 1];
-    }
-    if (i >= 1) sp_prev = sp_c[col_j + i - 1];
+  if (j + 1 < n) {
+    pm2_next = pm2_r[row_i + j + 1];
+    w_next = w_r[row_i + j + 1];
+  }
+  if (i >= 1) sp_prev = sp_c[col_j + i - 1];
+  float qa = kNegInf, mbc = 0.f, zpi = 0.f, zsj = 0.f, ztot = 0.f;
+  if (paired) {
+    qa = q.m[T_QA][row_i + j];
+    mbc = model.mbclose(s, n, i, j);
+    zpi = q.zp[i];
+    zsj = q.zs[j + 1];
+    ztot = q.zp[n];
   }
   Acc acc[3] = {acc_empty(), acc_empty(), acc_empty()};
   // [0] probs_multibranch (L_d): k = j+1 .. n-1, W(i,k) + Q1(j+1,k-1)
+#ifdef RNAMC_DEBUG_KNOBS
+  if (!(b.debug & 2))
+#endif
   if (j + 1 < n)
-    acc_product(acc[0], w_r + row_i + j + 1, q.m[T_Q1R] + static_cast<size_t>(j + 1) * ld + j, n - 1 - j);
+    acc_product<TPC>(acc[0], w_r + row_i + j + 1, q.m[T_Q1R] + static_cast<size_t>(j + 1) * ld + j,
+                     n - 1 - j, t);
   if (paired) {
-    // [1] enclosing 2-loops (574-593 / 681-700): (k,l) = (i-1-a, j+1+b)
-#pragma unroll
-    for (uint32_t p = t; p < 512u; p += kThreads) {
-      uint32_t a, bb;
-      if (probe_slot(p, a, bb) && a < i && j + 1u + bb < n) {
-        const uint32_t k = i - 1u - a, l = j + 1u + bb;
-        const float x = qb_r[static_cast<size_t>(k) * ld + l];
-        if (x > kNegInf) {
-          const float pkl = q.out[tri_off(n, l - k) + k];
-          acc_add(acc[1], ((pkl + qb) - x) + model.twoloop(s, k, l, i, j));
-        }
-      }
-    }
+    // [1] enclosing 2-loops
+    outer_block<CONTRA, TPC>(b, q, acc[1], i, j, t, qb);
     // [2] L_e cases one and three: k = 0 .. i-1, Q1(k+1,i-1) + R(k,j)
-    if (i >= 1) acc_product(acc[2], q.m[T_Q1C] + static_cast<size_t>(i - 1) * ld + 1, r_c + col_j, i);
+#ifdef RNAMC_DEBUG_KNOBS
+    if (!(b.debug & 2))
+#endif
+    if (i >= 1) acc_product<TPC>(acc[2], q.m[T_Q1C] + static_cast<size_t>(i - 1) * ld + 1, r_c + col_j, i, t);
   }
-  block_reduce<3>(acc, red);
-  if (t != 0) return;
+  if (!cell_reduce<3, TPC>(acc, red)) return;
 
+  const bool st = t == 0u;
   const float mb_un = CONTRA ? b.params->contra.multibranch_score_unpair : 0.f;
   const float pm = acc_value(acc[0]);
   const float pm2 = lse2(pm2_next + mb_un, w_next);
-  pm2_r[row_i + j] = pm2;
-  r_c[col_j + i] = lse2(pm, pm2);
-  sp_c[col_j + i] = lse2(sp_prev + mb_un, pm);
+  if (st) {
+    pm2_r[row_i + j] = pm2;
+    r_c[col_j + i] = lse2(pm, pm2);
+    sp_c[col_j + i] = lse2(sp_prev + mb_un, pm);
+  }
   if (!paired) return;
-  const float qa = q.m[T_QA][row_i + j];
-  const float ztot = q.zp[n];
   // exterior term (561-573 / 676-680)
-  float ext = CONTRA ? (((q.zp[i] + q.zs[j + 1]) + qa) + b.params->contra.external_score_basepair) - ztot
-                     : ((q.zp[i] + qa) + q.zs[j + 1]) - ztot;
+  const float ext = CONTRA ? (((zpi + zsj) + qa) + b.params->contra.external_score_basepair) - ztot
+                           : ((zpi + qa) + zsj) - ztot;
   Acc pa = acc[1];
   acc_add(pa, ext);
   // L_e: every term carries A = Qa + (coeff_num_branches | multibranch_score_basepair)
@@ -424,9 +871,173 @@ __global__ void __launch_bounds__(256) k_tree_outside(TreeBatch b, uint32_t d) {
   acc_add(pa, A + acc_value(acc[2]));
   acc_add(pa, A + sp_prev);  // case two: sp_prev holds the unpaired factors of rows k < i already
   const float lp = acc_value(pa);
-  if (lp > kNegInf) {
+  if (st && lp > kNegInf) {
     q.out[tri_off(n, d) + i] = lp;
-    q.m[T_ZRE][row_i + j] = (lp + model.mbclose(s, n, i, j)) - qb;
+    q.m[T_ZRE][row_i + j] = (lp + mbc) - qb;
+    reinterpret_cast<float2*>(q.m[T_PQ])[row_i + j] = make_float2(lp, qb);
+  }
+}
+
+// (+) over idx in [0, len0): three products off four streams
+//   pm0 += Wi[idx] + Qa[idx]          (cell (i,j):     k = j+1+idx)
+//   pmn += Wm[idx] + Qa[idx]          (cell (i-1,j),   do_n)
+//   pm1 += Wi[idx] + Qb[idx]          (cell (i,j+1):   idx >= 1, do_1)
+template <int TPC>
+__device__ __forceinline__ void acc_product_3(Acc& pm0, Acc& pmn, Acc& pm1,
+                                              const float* __restrict__ Wi,
+                                              const float* __restrict__ Wm,
+                                              const float* __restrict__ Qa,
+                                              const float* __restrict__ Qb, uint32_t len0, bool do_n,
+                                              bool do_1, uint32_t t) {
+  for (uint32_t k = t; k < len0; k += 2u * TPC) {
+    const uint32_t k1 = k + TPC;
+    const bool v1 = k1 < len0;
+    const float wi0 = Wi[k], wi1 = v1 ? Wi[k1] : kNegInf;
+    const float qa0 = Qa[k], qa1 = v1 ? Qa[k1] : kNegInf;
+    acc_add2(pm0, wi0 + qa0, wi1 + qa1);
+    if (do_n) {
+      const float wm0 = Wm[k], wm1 = v1 ? Wm[k1] : kNegInf;
+      acc_add2(pmn, wm0 + qa0, wm1 + qa1);
+    }
+    if (do_1) {
+      const float qb0 = k >= 1u ? Qb[k] : kNegInf, qb1 = v1 ? Qb[k1] : kNegInf;
+      acc_add2(pm1, wi0 + qb0, wi1 + qb1);
+    }
+  }
+}
+
+// diagonals d+1 (cell (i,j+1)) and d (cell (i,j)) of the outside sweep
+template <bool CONTRA, int TPC>
+__global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBatch b, uint32_t d) {
+  constexpr int BLOCK = TPC < 256 ? 256 : TPC;
+  constexpr int NA = 7;
+  __shared__ float red[BLOCK / 64][NA][2];
+#ifdef RNAMC_DEBUG_KNOBS
+  if (b.debug & 4) return;
+#endif
+  const TSeq q = load_tseq(b, blockIdx.y);
+  const uint32_t n = q.n, ld = q.ld;
+  const uint32_t i = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
+      static_cast<int>(blockIdx.x * (BLOCK / TPC) + threadIdx.x / TPC)));
+  if (i + d >= n) return;
+  const uint32_t j = i + d, j1 = j + 1u;
+  const bool has1 = j1 < n;
+  const uint32_t t = threadIdx.x % TPC;
+  const uint8_t* __restrict__ s = q.s;
+  const auto model = TModel<CONTRA>::make(b);
+  const float* __restrict__ qb_r = q.m[T_QB];
+  const size_t row_i = static_cast<size_t>(i) * ld, col_j = static_cast<size_t>(j) * ld;
+  const float* __restrict__ w_r = q.m[T_ZRE];   // W = (P + mbclose) - Qb, row-major
+  float* __restrict__ r_c = q.m[T_ZRM];         // R = Pm (+) Pm2, column-major
+  float* __restrict__ pm2_r = q.m[T_QM];        // probs_multibranch2, row-major
+  float* __restrict__ sp_c = q.m[T_U];          // sp_c(i,j) = (+)_{k<=i} Pm(k,j) [+ unpaired], column-major
+
+  const float qb0 = qb_r[row_i + j];
+  const float qb1 = has1 ? qb_r[row_i + j1] : kNegInf;
+  const bool paired0 = qb0 > kNegInf, paired1 = qb1 > kNegInf;  // (uniform)
+  // operands of the scalar recurrences, all from diagonals >= d+2
+  float pm2_next1 = kNegInf, w_next1 = kNegInf, sp_prev1 = kNegInf, sp_prev2 = kNegInf;
+  if (j1 + 1 < n) {
+    pm2_next1 = pm2_r[row_i + j1 + 1];  // Pm2(i, j+2)
+    w_next1 = w_r[row_i + j1 + 1];      // W(i, j+2)
+  }
+  if (i >= 1 && has1) sp_prev1 = sp_c[col_j + ld + i - 1];  // prefix of column j+1 up to row i-1
+  if (i >= 2) sp_prev2 = sp_c[col_j + i - 2];               // prefix of column j up to row i-2
+  float qa0 = kNegInf, mbc0 = 0.f, qa1 = kNegInf, mbc1 = 0.f;
+  const float ztot = q.zp[n], zpi = q.zp[i];
+  float zsj0 = 0.f, zsj1 = 0.f;
+  if (paired0) {
+    qa0 = q.m[T_QA][row_i + j];
+    mbc0 = model.mbclose(s, n, i, j);
+    zsj0 = q.zs[j + 1];
+  }
+  if (paired1) {
+    qa1 = q.m[T_QA][row_i + j1];
+    mbc1 = model.mbclose(s, n, i, j1);
+    zsj1 = q.zs[j1 + 1];
+  }
+  Acc acc[NA];
+#pragma unroll
+  for (int x = 0; x < NA; x++) acc[x] = acc_empty();
+  // [0] Pm(i,j), [1] Pm(i-1,j), [2] Pm(i,j+1): k = j+1 .. n-1 (the k = j+1 term of [0] reads
+  // W(i,j+1) of this launch next to Q1(j+1,j) = -inf: masked like [2]'s)
+#ifdef RNAMC_DEBUG_KNOBS
+  if (!(b.debug & 2))
+#endif
+  {
+    if (has1 && n - 1 - j >= 2)
+      acc_product_3<TPC>(acc[0], acc[1], acc[2], w_r + row_i + j1, w_r + row_i - ld + j1,
+                         q.m[T_Q1R] + static_cast<size_t>(j1) * ld + j,
+                         q.m[T_Q1R] + static_cast<size_t>(j1 + 1) * ld + j, n - 1 - j, i >= 1, true, t);
+    // [5] [6] L_e cases one and three of (i,j) and (i,j+1): k = 0 .. i-1, Q1(k+1,i-1) + R(k,.)
+    if (i >= 1 && (paired0 || paired1)) {
+      if (has1)
+        acc_product_2b<TPC>(acc[5], acc[6], q.m[T_Q1C] + static_cast<size_t>(i - 1) * ld + 1, r_c + col_j,
+                            r_c + col_j + ld, i - 1, i, t);
+      else
+        acc_product<TPC>(acc[5], q.m[T_Q1C] + static_cast<size_t>(i - 1) * ld + 1, r_c + col_j, i - 1, t);
+    }
+  }
+  // [3] [4] enclosing 2-loops
+  if (paired0) outer_block<CONTRA, TPC>(b, q, acc[3], i, j, t, qb0);
+  if (paired1) outer_block<CONTRA, TPC>(b, q, acc[4], i, j1, t, qb1);
+  if (!cell_reduce<NA, TPC>(acc, red)) return;
+
+  const bool st = t == 0u;
+  const float mb_un = CONTRA ? b.params->contra.multibranch_score_unpair : 0.f;
+  const float ext_bp = CONTRA ? b.params->contra.external_score_basepair : 0.f;
+  const float abr = CONTRA ? b.params->contra.multibranch_score_basepair
+                           : b.params->turner.coeff_num_branches;
+  // ---- cell (i,j+1)
+  float w1 = kNegInf, pm2_1 = kNegInf;
+  if (has1) {
+    const float pm1 = acc_value(acc[2]);
+    pm2_1 = lse2(pm2_next1 + mb_un, w_next1);
+    if (st) {
+      pm2_r[row_i + j1] = pm2_1;
+      r_c[col_j + ld + i] = lse2(pm1, pm2_1);
+      sp_c[col_j + ld + i] = lse2(sp_prev1 + mb_un, pm1);
+    }
+    if (paired1) {
+      const float ext = CONTRA ? (((zpi + zsj1) + qa1) + ext_bp) - ztot : ((zpi + qa1) + zsj1) - ztot;
+      Acc pa = acc[4];
+      acc_add(pa, ext);
+      const float A = qa1 + abr;
+      acc_add(pa, A + acc_value(acc[6]));
+      acc_add(pa, A + sp_prev1);
+      const float lp = acc_value(pa);
+      if (lp > kNegInf) {
+        w1 = (lp + mbc1) - qb1;
+        if (st) {
+          q.out[tri_off(n, d + 1) + i] = lp;
+          q.m[T_ZRE][row_i + j1] = w1;
+          reinterpret_cast<float2*>(q.m[T_PQ])[row_i + j1] = make_float2(lp, qb1);
+        }
+      }
+    }
+  }
+  // ---- cell (i,j); the prefix of column j up to row i-1 needs Pm(i-1,j) of this launch
+  const float pmn = acc_value(acc[1]);
+  const float sp_prev0 = i >= 1 ? lse2(sp_prev2 + mb_un, pmn) : kNegInf;
+  const float pm0 = acc_value(acc[0]);
+  const float pm2_0 = lse2(pm2_1 + mb_un, w1);
+  if (st) {
+    pm2_r[row_i + j] = pm2_0;
+    r_c[col_j + i] = lse2(pm0, pm2_0);
+    sp_c[col_j + i] = lse2(sp_prev0 + mb_un, pm0);
+  }
+  if (!paired0) return;
+  const float ext = CONTRA ? (((zpi + zsj0) + qa0) + ext_bp) - ztot : ((zpi + qa0) + zsj0) - ztot;
+  Acc pa = acc[3];
+  acc_add(pa, ext);
+  const float A = qa0 + abr;
+  acc_add(pa, A + acc_value(acc[5]));
+  acc_add(pa, A + sp_prev0);
+  const float lp = acc_value(pa);
+  if (st && lp > kNegInf) {
+    q.out[tri_off(n, d) + i] = lp;
+    q.m[T_ZRE][row_i + j] = (lp + mbc0) - qb0;
+    reinterpret_cast<float2*>(q.m[T_PQ])[row_i + j] = make_float2(lp, qb0);
   }
 }
 
@@ -455,22 +1066,70 @@ void launch_tree_init(const TreeBatch& b, uint32_t nseq, uint32_t max_n, bool co
   hipLaunchKernelGGL(k_tree_init, dim3(gx, nseq, 1), dim3(256), 0, st, b, contra ? 1 : 0, what);
 }
 
+// threads per cell by the number of cells of the diagonal (all sequences of the group): many
+// cells -> one wave each (four cells per workgroup, no barrier); few cells with long sums ->
+// 1024 threads each
+#define RNAMC_TREE_LAUNCH(K, C, T)                                                              \
+  hipLaunchKernelGGL((K<C, T>), dim3((cells + (T < 256 ? 256 / T : 1) - 1) / (T < 256 ? 256 / T : 1), nseq, 1), \
+                     dim3(T < 256 ? 256 : T), 0, st, b, d)
+static int tree_tpc(uint64_t cells, int64_t knob) {
+  if (knob == 64 || knob == 256 || knob == 1024) return static_cast<int>(knob);
+  return cells >= 2048 ? 64 : (cells >= 192 ? 256 : 1024);
+}
+
 void launch_tree_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
-                        hipStream_t st) {
-  const dim3 grid(max_n - d, nseq, 1);
-  if (contra)
-    hipLaunchKernelGGL(k_tree_inside<true>, grid, dim3(kThreads), 0, st, b, d);
-  else
-    hipLaunchKernelGGL(k_tree_inside<false>, grid, dim3(kThreads), 0, st, b, d);
+                        int64_t tpc_knob, bool two, hipStream_t st) {
+  const uint32_t cells = max_n - d;
+  const int tpc = tree_tpc(static_cast<uint64_t>(cells) * nseq, tpc_knob);
+  if (two) {
+    if (contra) {
+      if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_inside2, true, 64);
+      else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_inside2, true, 256);
+      else RNAMC_TREE_LAUNCH(k_tree_inside2, true, 1024);
+    } else {
+      if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_inside2, false, 64);
+      else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_inside2, false, 256);
+      else RNAMC_TREE_LAUNCH(k_tree_inside2, false, 1024);
+    }
+    return;
+  }
+  if (contra) {
+    if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_inside, true, 64);
+    else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_inside, true, 256);
+    else RNAMC_TREE_LAUNCH(k_tree_inside, true, 1024);
+  } else {
+    if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_inside, false, 64);
+    else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_inside, false, 256);
+    else RNAMC_TREE_LAUNCH(k_tree_inside, false, 1024);
+  }
 }
 
 void launch_tree_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
-                         hipStream_t st) {
-  const dim3 grid(max_n - d, nseq, 1);
-  if (contra)
-    hipLaunchKernelGGL(k_tree_outside<true>, grid, dim3(kThreads), 0, st, b, d);
-  else
-    hipLaunchKernelGGL(k_tree_outside<false>, grid, dim3(kThreads), 0, st, b, d);
+                         int64_t tpc_knob, bool two, hipStream_t st) {
+  const uint32_t cells = max_n - d;
+  const int tpc = tree_tpc(static_cast<uint64_t>(cells) * nseq, tpc_knob);
+  if (two) {
+    if (contra) {
+      if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_outside2, true, 64);
+      else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_outside2, true, 256);
+      else RNAMC_TREE_LAUNCH(k_tree_outside2, true, 1024);
+    } else {
+      if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_outside2, false, 64);
+      else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_outside2, false, 256);
+      else RNAMC_TREE_LAUNCH(k_tree_outside2, false, 1024);
+    }
+    return;
+  }
+  if (contra) {
+    if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_outside, true, 64);
+    else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_outside, true, 256);
+    else RNAMC_TREE_LAUNCH(k_tree_outside, true, 1024);
+  } else {
+    if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_outside, false, 64);
+    else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_outside, false, 256);
+    else RNAMC_TREE_LAUNCH(k_tree_outside, false, 1024);
+  }
+#undef RNAMC_TREE_LAUNCH
 }
 
 void launch_tree_finalize(const TreeBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st) {

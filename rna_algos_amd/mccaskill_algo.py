@@ -137,7 +137,7 @@ class Context:
 
     def stats(self):
         st = _lib.BatchStats()
-        _lib.check(_lib.lib().rnamc_ctx_last_stats(self._h, C.byref(st)))
+        _lib.check(_lib.lib().rnamc_ctx_stats(self._h, C.byref(st), C.sizeof(st), None))
         return {k: getattr(st, k) for k, _ in st._fields_}
 
     def bpp_batch(self, seqs, uses_contra_model, allows_short_hairpins):
@@ -208,6 +208,77 @@ class Context:
         return out
 
 
+class Pool:
+    """Owns one rnamc_pool: a device context per listed GPU (devices=None: every visible one);
+    `bpp_batch` shards a batch over them inside librnamc (rnamc_bpp_batch_multi), one host
+    thread per device, results written straight into the host triangles."""
+
+    def __init__(self, fold_score_sets, devices=None, workspace_bytes=0):
+        self._h = C.c_void_p()
+        self._key = fold_score_sets.content_key()
+        if devices is None:
+            arr, n = None, 0
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            n = len(devices)
+        _lib.check(_lib.lib().rnamc_pool_create(fold_score_sets.ptr, arr, n, workspace_bytes,
+                                                C.byref(self._h)))
+
+    def __len__(self):
+        return int(_lib.lib().rnamc_pool_size(self._h))
+
+    def sync_params(self, fold_score_sets):
+        key = fold_score_sets.content_key()
+        if key != self._key:
+            _lib.check(_lib.lib().rnamc_pool_set_params(self._h, fold_score_sets.ptr))
+            self._key = key
+
+    def set(self, name, value):
+        _lib.check(_lib.lib().rnamc_pool_set(self._h, name.encode(), int(value)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            try:
+                _lib.lib().rnamc_pool_destroy(self._h)
+            except Exception:
+                pass
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def bpp_batch(self, seqs, uses_contra_model, allows_short_hairpins):
+        for s in seqs:
+            if len(s) == 0:
+                raise _lib.RnamcError(_lib.ERR_EMPTY_SEQ)
+        lens = np.array([len(s) for s in seqs], dtype=np.uint64)
+        offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        np.cumsum(lens, out=offsets[1:])
+        bases = np.concatenate([np.asarray(s, dtype=np.uint8) for s in seqs]) if seqs else \
+            np.zeros(0, np.uint8)
+        out_offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        np.cumsum(lens * (lens + 1) // 2, out=out_offsets[1:])
+        bpp = np.empty(int(out_offsets[-1]), dtype=np.float32)
+        logz = np.empty(len(seqs), dtype=np.float32)
+        _lib.check(_lib.lib().rnamc_bpp_batch_multi(
+            self._h, len(seqs), bases.ctypes.data, offsets.ctypes.data, int(bool(uses_contra_model)),
+            int(bool(allows_short_hairpins)), bpp.ctypes.data, out_offsets.ctypes.data,
+            logz.ctypes.data))
+        mats = [BppMatrix(int(lens[s]), bpp[int(out_offsets[s]):int(out_offsets[s + 1])])
+                for s in range(len(seqs))]
+        return mats, logz
+
+
+def shard_plan(lengths, n_shards):
+    """rnamc_shard_plan: shard index of every sequence (host only, no device needed)."""
+    lens = np.asarray(lengths, dtype=np.uint64)
+    offsets = np.zeros(len(lens) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=offsets[1:])
+    out = np.zeros(len(lens), dtype=np.uint32)
+    _lib.check(_lib.lib().rnamc_shard_plan(len(lens), offsets.ctypes.data, int(n_shards),
+                                           out.ctypes.data))
+    return out
+
+
 # ONE device context per process for the module-level functions (workspace and staging
 # buffers are reused across calls).  The reference reads `&FoldScoreSets` on every call, and
 # the set is mutable: the tables are re-uploaded whenever their CONTENT differs from what the
@@ -250,8 +321,22 @@ def mccaskill_algo(seq, uses_contra_model, allows_short_hairpins, fold_score_set
     return mat.sparse(), FoldScores(materialise)
 
 
-def mccaskill_algo_batch(seqs, uses_contra_model, allows_short_hairpins, fold_score_sets):
-    """Whole FASTA at once (what src/bin/mccaskill_algo.rs:64-93 does on a thread pool)."""
+_pool = None
+
+
+def _pool_for(fold_score_sets):
+    global _pool
     with _ctx_lock:
-        return _context_for(fold_score_sets).bpp_batch(list(seqs), uses_contra_model,
-                                                       allows_short_hairpins)
+        if _pool is None:
+            _pool = Pool(fold_score_sets)  # every visible device
+        else:
+            _pool.sync_params(fold_score_sets)
+        return _pool
+
+
+def mccaskill_algo_batch(seqs, uses_contra_model, allows_short_hairpins, fold_score_sets):
+    """Whole FASTA at once, over every visible GPU (what src/bin/mccaskill_algo.rs:58-93 does on
+    all cores with one pool task per record)."""
+    with _ctx_lock:
+        return _pool_for(fold_score_sets).bpp_batch(list(seqs), uses_contra_model,
+                                                    allows_short_hairpins)

@@ -91,3 +91,21 @@ def test_durbin_cli_format(trnas, tmp_path):
     ii, jj = np.nonzero(want > 0)
     assert set(got) == set(zip(ii.tolist(), jj.tolist()))
     assert all(got[(i, j)] == want[i, j] for i, j in got)
+
+
+def test_durbin_more_pairs_than_one_launch_holds():
+    """all n(n-1)/2 pairs of a FASTA of many short records (what src/bin/durbin_algo.rs:55-75
+    submits): more than 65535 pairs, the grid-y limit of the match-probability kernel — the
+    batch entry must cut its chunks there as well as at the workspace cap."""
+    from rna_algos_amd.durbin_algo import AlignScores, durbin_algo_batch, with_pseudo_bases
+    rng = np.random.default_rng(5)
+    seqs = [with_pseudo_bases(rng.integers(0, 4, int(n))) for n in rng.integers(0, 3, 380)]
+    pairs = [(a, b) for a in range(len(seqs)) for b in range(a + 1, len(seqs))]
+    assert len(pairs) > 65535 + 4000
+    sc = AlignScores.new(0.0)
+    sc.transfer()
+    mats = durbin_algo_batch(seqs, pairs, sc)
+    assert len(mats) == len(pairs)
+    for x in list(range(0, len(pairs), 997)) + [65534, 65535, 65536, len(pairs) - 1]:
+        a, b = pairs[x]
+        same_bits(mats[x], O.durbin(sc.ptr, seqs[a], seqs[b]), f"pair {x} = ({a},{b})")

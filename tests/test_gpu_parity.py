@@ -750,3 +750,69 @@ def test_mid_size_group_default_knobs(params, contra):
     for s, g, r in zip(seqs, got, ref):
         assert_same(g.packed, r, f"n={len(s)}")
     assert np.array_equal(np.asarray(logz).view(np.uint32), np.asarray(ref_logz).view(np.uint32))
+
+
+def test_pool_two_contexts_one_gpu(params, ctx):
+    """rnamc_bpp_batch_multi with devices = {0, 0}: two contexts (and two host threads) on one
+    GPU, small workspaces; bit-identical to the single-context result on a ragged batch, log
+    partition functions in the caller's order; one bad record fails the call with its status
+    before any device is touched, and the pool still works afterwards."""
+    from rna_algos_amd import _lib
+    from rna_algos_amd.mccaskill_algo import Pool, shard_plan
+    rng = np.random.default_rng(17)
+    lens = [5, 900, 37, 412, 411, 64, 1, 300, 299, 150, 700, 33, 650, 20, 128]
+    seqs = [rng.integers(0, 4, n).astype(np.uint8) for n in lens]
+    pool = Pool(params, devices=[0, 0], workspace_bytes=256 << 20)
+    try:
+        assert len(pool) == 2
+        plan = shard_plan(lens, 2)
+        assert set(plan.tolist()) == {0, 1}
+        for contra in (False, True):
+            mats, logz = pool.bpp_batch(seqs, contra, False)
+            ref, ref_z = ctx.bpp_batch(seqs, contra, False)
+            for s, a, b in zip(seqs, mats, ref):
+                assert np.array_equal(a.packed, b.packed), f"n={len(s)} contra={contra}"
+            assert np.array_equal(logz, ref_z)
+        # error paths: statuses of rnamc_bpp_batch, nothing computed, pool usable afterwards
+        bad = list(seqs)
+        bad[3] = np.array([0, 1, 7, 2], dtype=np.uint8)
+        with pytest.raises(_lib.RnamcError) as e:
+            pool.bpp_batch(bad, False, False)
+        assert e.value.status == _lib.ERR_INVALID_BASE
+        with pytest.raises(_lib.RnamcError) as e:
+            pool.bpp_batch(seqs[:2] + [np.zeros(0, dtype=np.uint8)], False, False)
+        assert e.value.status == _lib.ERR_EMPTY_SEQ
+        mats, logz = pool.bpp_batch(seqs[:3], False, False)
+        ref, ref_z = ctx.bpp_batch(seqs[:3], False, False)
+        assert all(np.array_equal(a.packed, b.packed) for a, b in zip(mats, ref))
+        # a knob set on the pool reaches every context: tree-order sums on both shards
+        pool.set("summation_mode", 1)
+        mt, zt = pool.bpp_batch(seqs, False, False)
+        pool.set("summation_mode", 0)
+        for a, b in zip(mt, ref_all := ctx.bpp_batch(seqs, False, False)[0]):
+            ka, kb = np.asarray(a.packed) >= -0.5, np.asarray(b.packed) >= -0.5
+            assert np.array_equal(ka, kb)
+            assert np.max(np.abs(np.asarray(a.packed)[ka] - np.asarray(b.packed)[ka]), initial=0.0) < 2e-2
+    finally:
+        pool.close()
+
+
+def test_librnamc_first_then_torch():
+    """Init order (the round-2 "No HIP GPUs are available").  Cause:
+    torch ships its own libamdhip64.so + libhsa-runtime64.so; librnamc.so needs
+    `libamdhip64.so.7`.  Loaded FIRST, librnamc pulls in /opt/rocm's runtime; torch then loads its
+    bundled pair as a SECOND HSA runtime in the process, which finds no GPU (one KFD client per
+    process).  Loaded after torch, librnamc's NEEDED entry is satisfied by torch's copy (same
+    SONAME) and there is one runtime.  rna_algos_amd._lib therefore preloads torch's bundled
+    runtime (when torch is installed) before librnamc.so, which makes either order work; this
+    test runs the bad order in a fresh process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "init_order_probe.py"), "rnamc_first"],
+                         capture_output=True, text=True, timeout=600)
+    text = out.stdout + out.stderr
+    assert "FAILED" not in text and "torch: (True, 4.0)" in text and "rnamc again:" in text, text
+    # one HIP runtime in the process
+    mapped = [ln for ln in text.splitlines() if ln.strip().startswith("mapped:")][-1]
+    assert mapped.count("libamdhip64") == 1, mapped

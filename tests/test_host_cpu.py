@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(built):
     for sym in sorted(declared):
         assert hasattr(L, sym), f"librnamc.so lacks {sym}"
     assert set(_lib.SYMBOLS) == declared
-    assert L.rnamc_abi_version() == 2
+    assert L.rnamc_abi_version() == 3
     assert L.rnamc_params_sizeof() > 300000
 
 
@@ -218,3 +218,39 @@ def test_params_setters_for_foreign_hosts(built):
     assert L.rnamc_params_set_special_hairpins(P.ptr, 65, seqs.ctypes.data, lens.ctypes.data,
                                                scores.ctypes.data) != 0
     assert L.rnamc_params_set_hairpin_limits(P.ptr, 3, 31, 10) != 0
+
+
+def test_shard_plan_partitions_and_balances(built):
+    """rnamc_shard_plan (the partition behind rnamc_bpp_batch_multi): every sequence lands in
+    exactly one shard, shards are bands of the length-sorted batch, loads under the cost model
+    are level, and the result equals bench.py's shard_banded on the 10k-batch lengths."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from rna_algos_amd import workloads as W
+    from rna_algos_amd.mccaskill_algo import shard_plan
+    lens = W.batch_lengths(10000)
+    costs = W.sweep_cost(lens)
+    for world in (1, 2, 3, 4, 8):
+        plan = shard_plan(lens, world)
+        assert plan.shape == (10000,) and plan.min() == 0 and plan.max() == world - 1
+        want = np.empty(10000, dtype=np.uint32)
+        for r, idx in enumerate(bench.shard_banded(costs, world)):
+            want[idx] = r
+        assert np.array_equal(plan, want)
+        loads = np.array([costs[plan == r].sum() for r in range(world)])
+        assert loads.max() / loads.min() < 1.01
+        # bands: every member of shard r is at least as long as every member of shard r+1
+        for r in range(world - 1):
+            assert lens[plan == r].min() >= lens[plan == r + 1].max()
+    # a few sequences of very different cost: one per shard, none left empty
+    assert shard_plan([100, 300, 200], 3).tolist() == [2, 0, 1]
+    assert sorted(shard_plan([2000, 300, 250, 200, 100], 4).tolist()) == [0, 1, 2, 3, 3]
+    for world in (2, 3, 5):
+        small = [900, 50, 40, 30, 20, 10, 5]
+        want = np.empty(len(small), dtype=np.uint32)
+        for r, idx in enumerate(bench.shard_banded(W.sweep_cost(np.array(small)), world)):
+            want[idx] = r
+        assert np.array_equal(shard_plan(small, world), want)
+    assert shard_plan([77], 4).tolist() == [0]
+    assert shard_plan([], 4).shape == (0,)

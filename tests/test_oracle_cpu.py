@@ -234,3 +234,27 @@ def test_fold_scores_key_sets(params, trnas, contra, short):
                             break
                         want += bool(member[k, l])
         assert want == len(tl)
+
+
+def test_exact_evaluation_against_bruteforce(params):
+    """oracle/mccaskill_exact.c (the restatement's loops with Score = double and an exact
+    logsumexp; the checker of the HIP path's tree-order mode) against the exhaustive f64
+    enumeration: the two must agree to f64-level accuracy of f32 tables, and the f32
+    reference-order restatement must sit farther from both (its logsumexp is a cubic fit)."""
+    for n, seed in [(9, 11), (13, 12), (16, 13), (18, 14)]:
+        for contra, short in [(False, False), (True, False), (True, True)]:
+            s = O.splitmix_seq(n, seed)
+            ez, full, cnt = O.bruteforce(params.ptr, s, contra, short)
+            xb, xz = O.exact_bpp(params.ptr, s, contra, short)
+            rb, rz = O.bpp(params.ptr, s, contra, short)
+            assert abs(xz - ez) <= 1e-6 * max(1.0, abs(ez))
+            o = 0
+            for d in range(n):
+                for i in range(n - d):
+                    v = xb[o]
+                    if full[i, i + d] > 0:
+                        assert v >= 0 and abs(v - full[i, i + d]) <= 1e-6
+                    else:
+                        assert v < 0 or v <= 1e-30
+                    assert (rb[o] >= -0.5) == (v >= -0.5)  # same key set as the reference restatement
+                    o += 1

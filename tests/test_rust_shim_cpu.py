@@ -14,7 +14,7 @@ DUMPER = os.path.join(ROOT, "bindings", "rust", "dump_tables.rs")
 HEADER = os.path.join(ROOT, "include", "rnamc.h")
 
 # opaque / struct pointees that correspond across the boundary
-OPAQUE = {"rnamc_ctx": "ctx", "RnamcCtx": "ctx", "rnamc_params": "void", "c_void": "void",
+OPAQUE = {"rnamc_ctx": "ctx", "RnamcCtx": "ctx", "rnamc_pool": "pool", "RnamcPool": "pool", "rnamc_params": "void", "c_void": "void",
           "void": "void", "rnamc_twoloop_score": "twoloop", "TwoloopScore": "twoloop",
           "rnamc_fold_score_sets": "void", "rnamc_batch_stats": "stats",
           "rnamc_align_scores": "align", "AlignScoresC": "align"}
@@ -142,6 +142,25 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(L, n), n
 
 
+def test_batch_stats_struct_matches_header():
+    """the ctypes mirror of rnamc_batch_stats has the header's fields in order (a binding of an
+    older header is protected by rnamc_ctx_stats' size argument; this one must be current)"""
+    from rna_algos_amd import _lib
+    hdr = re.sub(r"/\*.*?\*/", " ", open(HEADER).read(), flags=re.S)
+    body = re.search(r"typedef struct rnamc_batch_stats \{(.*?)\} rnamc_batch_stats;", hdr, flags=re.S).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ty, names = decl.split(None, 1)
+        for nm in names.split(","):
+            fields.append((nm.strip(), ty))
+    want = {"uint64_t": "c_ulong", "double": "c_double"}
+    got = [(n, t.__name__) for n, t in _lib.BatchStats._fields_]
+    assert got == [(n, want[t]) for n, t in fields]
+
+
 def test_twoloop_struct_matches():
     src = open(SHIM).read()
     body = re.search(r"pub struct TwoloopScore \{(.*?)\}", src, flags=re.S).group(1)
@@ -158,7 +177,9 @@ def test_shim_keeps_reference_semantics():
     src = open(SHIM).read()
     code = re.sub(r"//[^\n]*", "", src)
     assert "OnceLock" not in code
-    assert "content_key(fold_score_sets)" in code and "rnamc_ctx_set_params" in code
+    assert "content_key(fold_score_sets)" in code and "rnamc_pool_set_params" in code
+    # the batch entry drives EVERY visible device (n_devices = 0), not the current one alone
+    assert "rnamc_bpp_batch_multi" in code and re.search(r"rnamc_pool_create\(p,\s*std::ptr::null\(\),\s*0,", code)
     assert 'cfg!(feature = "no-fold-scores")' in code and 'feature = "fold-scores"' not in code
     assert "panic!()" not in code and "rnamc_last_error" in code
     assert "pub fn mccaskill_algo_batch<T>" in code
