@@ -374,7 +374,7 @@ int rnamc_centroid_fold(const float* bpp_packed, uint32_t n, float centroid_thre
 
 /* ------------------------------------------------------------------------- */
 /* Durbin pair-HMM nucleotide match probabilities (SURVEY.md 8f-4;
- * reference: src/durbin_algo.rs:73-264, constants src/compiled_align_scores.rs). */
+ * reference: src/durbin_algo.rs:73-242, constants src/compiled_align_scores.rs). */
 
 /* AlignScores (src/durbin_algo.rs:4-14). */
 typedef struct rnamc_align_scores {

@@ -3,8 +3,8 @@
  * TEST INFRASTRUCTURE ONLY: loaded by tests/, never by the product (rna_algos_amd/).
  *
  * Follows /root/reference/src/durbin_algo.rs loop for loop:
- *   get_align_sums   90-215  (forward 92-151, backward 152-213)
- *   get_match_probs  217-264
+ *   get_align_sums   79-199  (forward 82-139, backward 140-197)
+ *   get_match_probs  201-242
  * with logsumexp / expf of src/utils.rs:579-655 (oracle_scoring.h).  f32 throughout, no FMA
  * contraction.  Unlike the McCaskill path, every constant of this path is in the reference
  * tree itself (src/compiled_align_scores.rs); the caller passes them in rnamc_align_scores.

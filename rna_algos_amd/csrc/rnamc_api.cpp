@@ -715,71 +715,34 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
   return RNAMC_OK;
 }
 
-// Tables of the tree-order 2-loop scorer (TreeTabs, rnamc_device.h), from the parameter block.
-// Turner: get_bulge_score / get_interior_score (src/utils.rs:234-321, 331-366); CONTRAfold:
-// get_bulge_score_contra / get_interior_score_contra (456-520) + the enclosed pair's
-// base-pair score (src/mccaskill_algo.rs:441).
+// Length-dependent part of the generic 2-loop scores of the tree-order mode (TreeTabs), from
+// the parameter block.  Turner: bulge_scores_init[len] | interior_scores_init[len] +
+// max(ninio_coeff * |a-b|, ninio_max) (src/utils.rs:234-321); CONTRAfold: the cumulative
+// bulge / interior length, symmetric / asymmetric and explicit terms (456-520).
 void build_tree_tabs(const rnamc_params& P, TreeTabs& T) {
   std::memset(&T, 0, sizeof(T));
   const rnamc_turner_scores& t = P.turner;
   const rnamc_fold_score_sets& f = P.contra;
-  auto pen = [&](int a, int b) { return augu(a, b) ? t.helix_augu_end_penalty : 0.f; };
-  const float(*tmx[4])[4][4][4] = {nullptr, t.terminal_mismatch_scores_1xmany,
-                                   t.terminal_mismatch_scores_2x3, t.terminal_mismatch_scores_interior};
-  for (int c = 0; c < 4; c++)
-    for (int x = 0; x < 256; x++) {
-      const int b0 = x & 3, b1 = (x >> 2) & 3, b2 = (x >> 4) & 3, b3 = (x >> 6) & 3;
-      {  // inside: x = m3 + 4 ak + 16 al + 64 m2
-        const int m3 = b0, ak = b1, al = b2, m2 = b3;
-        T.in[0][c][x] = c == 0 ? pen(ak, al) : tmx[c][al][ak][m2][m3] + pen(ak, al);
-        T.in[1][c][x] = (f.helix_close_scores[al][ak] + f.terminal_mismatch_scores[al][ak][m2][m3]) +
-                        f.basepair_scores[ak][al];
-      }
-      {  // outside: x = ck + 4 x1 + 16 y1 + 64 cl
-        const int ck = b0, x1 = b1, y1 = b2, cl = b3;
-        T.out[0][c][x] = c == 0 ? pen(ck, cl) : tmx[c][ck][cl][x1][y1] + pen(ck, cl);
-        T.out[1][c][x] = f.helix_close_scores[ck][cl] + f.terminal_mismatch_scores[ck][cl][x1][y1];
-      }
-    }
   for (uint32_t p = 0; p < 512; p++) {
     const uint32_t r = p >> 5, c = p & 31u;
     const bool first = c < 31u - r;
     const uint32_t a = first ? r : 30u - r, b = first ? c : c - (31u - r);
-    const bool valid = r < 15u || c < 16u;
+    if (!(r < 15u || c < 16u)) continue;  // not a probe slot
     const uint32_t len = a + b, diff = a > b ? a - b : b - a;
     const bool bulge = (a == 0u) != (b == 0u);
-    for (int m = 0; m < 2; m++) {
-      uint32_t kind = valid ? 1u : 0u, cls = 0;
-      float lv = 0.f;
-      if (valid) {
-        const bool special = m == 0 ? (len == 0u || (bulge && len == 1u) || (a >= 1u && a <= 2u && b >= 1u && b <= 2u))
-                                    : (a <= 1u && b <= 1u);
-        if (special) {
-          kind = 2u;
-        } else if (m == 0) {
-          if (bulge) {
-            cls = 0;
-            lv = t.bulge_scores_init[len];
-          } else {
-            cls = (a == 1u || b == 1u) ? 1u : (((a == 2u && b == 3u) || (a == 3u && b == 2u)) ? 2u : 3u);
-            const float nin = t.ninio_coeff * static_cast<float>(diff);
-            lv = t.interior_scores_init[len] + (nin > t.ninio_max ? nin : t.ninio_max);
-          }
-        } else {
-          if (bulge) {
-            lv = f.bulge_scores_len_cumulative[len - 1u];
-          } else {
-            const float s0 = (a == b) ? f.interior_scores_symmetric_cumulative[a - 1u]
-                                      : f.interior_scores_asymmetric_cumulative[diff - 1u];
-            const float se = (a <= RNAMC_MAX_INTERIOR_EXPLICIT && b <= RNAMC_MAX_INTERIOR_EXPLICIT)
-                                 ? f.interior_scores_explicit[a - 1u][b - 1u]
-                                 : 0.f;
-            lv = (s0 + se) + f.interior_scores_len_cumulative[len - 2u];
-          }
-        }
-      }
-      T.len[m][p] = lv;
-      T.slot[m][p] = a | (b << 8) | (cls << 16) | (kind << 24);
+    if (len < 2u) continue;  // stack / 0x1: scored by the flat scorers
+    if (bulge) {
+      T.len[0][p] = t.bulge_scores_init[len];
+      T.len[1][p] = f.bulge_scores_len_cumulative[len - 1u];
+    } else if (a >= 1u && b >= 1u) {
+      const float nin = t.ninio_coeff * static_cast<float>(diff);
+      T.len[0][p] = t.interior_scores_init[len] + (nin > t.ninio_max ? nin : t.ninio_max);
+      const float s0 = (a == b) ? f.interior_scores_symmetric_cumulative[a - 1u]
+                                : f.interior_scores_asymmetric_cumulative[diff - 1u];
+      const float se = (a <= RNAMC_MAX_INTERIOR_EXPLICIT && b <= RNAMC_MAX_INTERIOR_EXPLICIT)
+                           ? f.interior_scores_explicit[a - 1u][b - 1u]
+                           : 0.f;
+      T.len[1][p] = (s0 + se) + f.interior_scores_len_cumulative[len - 2u];
     }
   }
 }
@@ -932,7 +895,8 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
     };
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 0], st));
     launch_tree_init(b, nseq, gmax, contra, 0, st);
-    c->stats.launches_other++;
+    launch_tree_static(b, contra, nseq, gmax, st);
+    c->stats.launches_other += 2;
     const bool two = c->tree_two != 0;
     for (uint32_t d = dmin_in; d < gmax; d += two ? 2 : 1) {
       launch_tree_inside(b, contra, d, gmax, active(d), c->tree_tpc, two, st);

@@ -68,7 +68,7 @@ void launch_outside_lat(const DeviceBatch& b, bool contra, uint32_t d, uint32_t 
 // closing-pair block (inside) / 2-loop half of the pair probabilities (outside) of diagonal d
 void launch_pair_lat(const DeviceBatch& b, bool contra, bool outside, uint32_t d, uint32_t max_n,
                      uint32_t nseq, hipStream_t st);
-// Durbin pair-HMM (src/durbin_algo.rs:90-264): one pair of sequences
+// Durbin pair-HMM (src/durbin_algo.rs:79-242): one pair of sequences
 struct DurbinPair {
   uint32_t n1, n2;   // lengths including the two pseudo bases
   uint64_t a_off, b_off;  // offsets of the two sequences in the bases buffer
@@ -93,19 +93,20 @@ enum TreeMat : int {
   T_ZRM = 5,  // sums_rightmost_basepairs_multibranch         col | outside: R = Pm (+) Pm2, col
   T_QM = 6,   // sums_multibranch                             row | outside: probs_multibranch2, row
   T_U = 7,    // column prefix of Zr_mb (first fold of L_c)   col | outside: column prefix of Pm, col
-  T_PQ = 8,   // outside: {log bpp, sums_close} of a finished pair, interleaved float2, row (two slots)
-  T_COUNT = 10
+  T_HP = 8,    // hairpin score of the pair (static)                        row
+  T_MBC = 9,   // multibranch_close score; -inf = (i,j) may not pair (static) row
+  T_X4 = 10,   // float4 per cell, row (four slots): inside QbX4 = sums_close + IN4,
+               // outside PX4 = (log bpp - sums_close) + CS4
+  T_ACCS = 14, // accessible score (static)                                  row
+  T_CS4 = 15,  // float4 per cell, row: the pair as CLOSING pair of a generic 2-loop, by class (static)
+  T_IN4 = 19,  // float4 per cell, row: the pair as ENCLOSED pair (static)
+  T_COUNT = 23
 };
-// Tables of the tree-order 2-loop scorer, derived from rnamc_params on the host
-// (rnamc_api.cpp, build_tree_tabs).  Model index 0 Turner, 1 CONTRAfold.  A generic 2-loop
-// (bulge or interior loop that is not one of the few small explicit ones) scores as
-//   len[slot] + side_of_the_fixed_pair[cls] + table[cls][bases of the varying pair]
-// with cls in {0 bulge, 1 1 x many, 2 2 x 3, 3 other interior} (CONTRAfold: rows alike).
+// Length-dependent part of a generic 2-loop score per probe slot (rnamc_tree.hip, probe_slot),
+// derived from rnamc_params on the host (rnamc_api.cpp, build_tree_tabs).  Model index 0 Turner,
+// 1 CONTRAfold.
 struct TreeTabs {
-  float in[2][4][256];    // varying = enclosed pair (inside sweep): [cls][m3 + 4 ak + 16 al + 64 m2]
-  float out[2][4][256];   // varying = closing pair (outside sweep): [cls][ck + 4 x1 + 16 y1 + 64 cl]
-  float len[2][512];      // per probe slot: the length-dependent part
-  uint32_t slot[2][512];  // a | b << 8 | cls << 16 | kind << 24; kind 0 no probe, 1 generic, 2 special
+  float len[2][512];
 };
 struct TreeSeq {
   uint32_t n, ld;
@@ -141,6 +142,8 @@ void launch_tree_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t ma
                         int64_t tpc_knob, bool two, hipStream_t st);
 void launch_tree_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
                          int64_t tpc_knob, bool two, hipStream_t st);
+// per-cell statics (hairpin / multibranch-close / accessible scores, 2-loop sides), once per group
+void launch_tree_static(const TreeBatch& b, bool contra, uint32_t nseq, uint32_t max_n, hipStream_t st);
 void launch_tree_finalize(const TreeBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st);
 
 }  // namespace rnamc

@@ -1583,7 +1583,7 @@ __global__ void __launch_bounds__(64) k_outside_lat(DeviceBatch b, uint32_t d, u
 }
 
 // ----------------------------------------------------------------------------
-// Durbin pair-HMM (src/durbin_algo.rs:90-264): forward and backward sums of one sequence
+// Durbin pair-HMM (src/durbin_algo.rs:79-242): forward and backward sums of one sequence
 // pair by anti-diagonal (cell (i,j) needs (i-1,j-1), (i-1,j), (i,j-1) resp. the +1
 // neighbours), one workgroup per (pair, direction), lanes = cells of the diagonal; then the
 // match probabilities, one lane per cell.  Six row-major n1 x n2 matrices per pair in the
@@ -1682,7 +1682,7 @@ __global__ void __launch_bounds__(kDurbinThreads)
   }
 }
 
-// get_match_probs (src/durbin_algo.rs:217-264)
+// get_match_probs (src/durbin_algo.rs:201-242)
 __global__ void __launch_bounds__(256)
     k_durbin_probs(const DurbinPair* __restrict__ pairs, const float* __restrict__ ws,
                    float* __restrict__ out, rnamc_align_scores sc) {

@@ -54,6 +54,21 @@ __device__ __forceinline__ float vmaxf(float a, float b) {
   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+// Wave-uniform loads through the scalar unit (s_load): the operand sits at an address every lane
+// of the wave shares, and it was written by an EARLIER launch (the scalar cache is invalidated
+// at every kernel start like the vector L1).  A wave's uniform operands then cost the vector
+// memory pipeline nothing, which matters: a launch runs thousands of waves that each need ~40.
+__device__ __forceinline__ float sload(const float* p) {
+  return *reinterpret_cast<const __attribute__((address_space(4))) float*>(reinterpret_cast<uintptr_t>(p));
+}
+__device__ __forceinline__ uint32_t sload(const uint32_t* p) {
+  return *reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(reinterpret_cast<uintptr_t>(p));
+}
+__device__ __forceinline__ float4 sload4(const float4* p) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f v = *reinterpret_cast<const __attribute__((address_space(4))) v4f*>(reinterpret_cast<uintptr_t>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float lg2(float x) { return __builtin_amdgcn_logf(x); }
 
@@ -162,17 +177,22 @@ __device__ __forceinline__ bool cell_reduce(Acc (&a)[NA], float (*lds)[NA][2]) {
 }
 
 // (+)_k (A[k] + B[k]) over k in [0, len): both operands contiguous in k, the cell's TPC
-// lanes take consecutive k (256-B wave accesses), four loads of each operand in flight.
+// lanes take consecutive k (256-B wave accesses).  The sweep's launches are bound by how many
+// bytes their waves keep in flight (a wave that waits for one load per step streams at a few
+// per cent of the HBM rate): every lane issues the loads of FOUR steps of every stream before
+// it folds the first.
 template <int TPC>
 __device__ __forceinline__ void acc_product(Acc& a, const float* __restrict__ A,
                                             const float* __restrict__ B, uint32_t len, uint32_t t) {
-  for (uint32_t k = t; k < len; k += 4u * TPC) {
-    const uint32_t k1 = k + TPC, k2 = k + 2u * TPC, k3 = k + 3u * TPC;
-    const float a0 = A[k], b0 = B[k];
-    const float a1 = k1 < len ? A[k1] : kNegInf, b1 = k1 < len ? B[k1] : kNegInf;
-    const float a2 = k2 < len ? A[k2] : kNegInf, b2 = k2 < len ? B[k2] : kNegInf;
-    const float a3 = k3 < len ? A[k3] : kNegInf, b3 = k3 < len ? B[k3] : kNegInf;
-    acc_add4(a, a0 + b0, a1 + b1, a2 + b2, a3 + b3);
+  for (uint32_t k = t; k < len; k += 8u * TPC) {
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const uint32_t ku = k + static_cast<uint32_t>(u) * TPC;
+      x[u] = ku < len ? A[ku] + B[ku] : kNegInf;
+    }
+    acc_add4(a, x[0], x[1], x[2], x[3]);
+    acc_add4(a, x[4], x[5], x[6], x[7]);
   }
 }
 
@@ -213,7 +233,7 @@ __device__ __forceinline__ uint32_t tri_off(uint32_t n, uint32_t d) {
 __device__ __forceinline__ uint64_t load_win64(const uint32_t* __restrict__ pk, int p0) {
   const uint32_t bit = 2u * static_cast<uint32_t>(p0 + 32);
   const uint32_t w = bit >> 5, sh = bit & 31u;
-  const uint32_t w0 = pk[w], w1 = pk[w + 1], w2 = pk[w + 2];
+  const uint32_t w0 = sload(pk + w), w1 = sload(pk + w + 1), w2 = sload(pk + w + 2);  // (p0 is uniform)
   const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
   const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
   return (static_cast<uint64_t>(hi) << 32) | lo;
@@ -263,8 +283,9 @@ __global__ void __launch_bounds__(256) k_tree_init(TreeBatch b, int contra, int 
   const size_t t0 = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (what == 0) {
     // FoldSums::new (src/mccaskill_algo.rs:213-226): every sparse / dense sum starts absent
+    // (the statics CS4 / IN4 / ACCS are read only where MBC says "may pair": any finite filler)
     const size_t total = static_cast<size_t>(T_COUNT) * sd.msz;
-    for (size_t x = t0; x < total; x += stride) base[x] = kNegInf;
+    for (size_t x = t0; x < total; x += stride) base[x] = (x / sd.msz) >= T_ACCS ? 0.f : kNegInf;
     float* out = b.out + sd.out_off;
     const size_t olen = static_cast<size_t>(sd.n) * (sd.n + 1u) / 2u;
     for (size_t x = t0; x < olen; x += stride) out[x] = kNegInf;
@@ -289,9 +310,9 @@ __global__ void __launch_bounds__(256) k_tree_init(TreeBatch b, int contra, int 
       pk[wd] = v;
     }
   } else {
-    // the four slots the outside sweep reuses (W, R, Pm2, SP)
-    const int mats[4] = {T_ZRE, T_ZRM, T_QM, T_U};
-    for (int y = 0; y < 4; y++) {
+    // the slots the outside sweep reuses (W, R, Pm2, SP, and PX4 in place of QbX4)
+    const int mats[8] = {T_ZRE, T_ZRM, T_QM, T_U, T_X4, T_X4 + 1, T_X4 + 2, T_X4 + 3};
+    for (int y = 0; y < 8; y++) {
       float* p = base + static_cast<size_t>(mats[y]) * sd.msz;
       for (size_t x = t0; x < sd.msz; x += stride) p[x] = kNegInf;
     }
@@ -299,13 +320,23 @@ __global__ void __launch_bounds__(256) k_tree_init(TreeBatch b, int contra, int 
 }
 
 // ----------------------------------------------------------------------------
-// 2-loop terms.  The <= 496 probes of a cell sit in 512 slots spread over the cell's lanes.  A
-// generic loop costs a table lookup: length part of the slot + the fixed pair's side (uniform
-// over the cell, by class) + the varying pair's side from a 256-entry table indexed by the four
-// bases around that pair, which are adjacent 2-bit fields of the two base windows.  The few
-// small loops with explicit tables (Turner: stack, 0x1, 1x1, 1x2, 2x1, 2x2; CONTRAfold: stack,
-// 0x1, 1x1) are scored by the flat scorers of rnamc_scoring.h in one extra pass of the cell's
-// first lanes.
+// Per-cell statics (functions of the sequence alone), written once per sequence by
+// k_tree_static so that the sweep's launches find them with ONE load each: a launch's duration
+// is the length of its waves' chain of dependent memory round trips, and scores looked up
+// through base codes (bases -> table) would add two levels to it.
+//   HP, MBC, ACCS : hairpin, multibranch-close and accessible score of the pair (i,j); MBC is
+//                   -inf where (i,j) may not pair (the `act` flag of the sweep)
+//   CS4(i,j)      : the pair as the CLOSING pair of a generic 2-loop, by class: Turner
+//                   pen | mismatch_c[si][sj][s(i+1)][s(j-1)] + pen; CONTRAfold helix_close +
+//                   terminal_mismatch
+//   IN4(i,j)      : the pair as the ENCLOSED pair: mismatch_c[sj][si][s(j+1)][s(i-1)] + pen
+//                   (CONTRAfold: + base-pair score)
+// A generic 2-loop (i,j) around (k,l) then scores  len[slot] + CS4(i,j)[c] + IN4(k,l)[c]  with
+// c = class of the slot; the sweep stores  QbX4(k,l) = sums_close(k,l) + IN4(k,l)  (inside) and
+// PX4(k,l) = (log bpp - sums_close)(k,l) + CS4(k,l)  (outside) as float4 per cell, so a probe is
+// one 16-byte gather.  The few small loops with explicit tables (Turner: stack, 0x1, 1x1, 1x2,
+// 2x1, 2x2; CONTRAfold: stack, 0x1, 1x1) depend on both pairs at once: the flat scorers of
+// rnamc_scoring.h score them in one extra pass of the cell's first lanes.
 template <bool CONTRA>
 struct Special;
 template <>
@@ -316,250 +347,190 @@ struct Special<false> {
     a = t < 2u ? 0u : (t < 5u ? 1u : 2u);
     bb = t == 0u ? 0u : (t == 1u ? 1u : (t == 2u ? 0u : (t == 3u ? 1u : (t == 4u ? 2u : (t == 5u ? 1u : 2u)))));
   }
+  static __device__ __forceinline__ bool is(uint32_t a, uint32_t bb) {
+    return (a + bb <= 1u) || (a >= 1u && a <= 2u && bb >= 1u && bb <= 2u);
+  }
 };
 template <>
 struct Special<true> {
   static constexpr uint32_t N = 4;
   static __device__ __forceinline__ void slot(uint32_t t, uint32_t& a, uint32_t& bb) {
-    // (0,0) (0,1) (1,0) (1,1)
-    a = t >> 1;
+    a = t >> 1;  // (0,0) (0,1) (1,0) (1,1)
     bb = t & 1u;
   }
+  static __device__ __forceinline__ bool is(uint32_t a, uint32_t bb) { return a <= 1u && bb <= 1u; }
 };
 
-__device__ __forceinline__ float sel4(uint32_t c, float v0, float v1, float v2, float v3) {
-  return c == 0u ? v0 : (c == 1u ? v1 : (c == 2u ? v2 : v3));
+// class of a generic slot: 0 bulge, 1 1 x many, 2 2 x 3, 3 other interior
+__device__ __forceinline__ uint32_t slot_class(uint32_t a, uint32_t bb) {
+  if ((a == 0u) != (bb == 0u)) return 0u;
+  if (a == 1u || bb == 1u) return 1u;
+  if ((a == 2u && bb == 3u) || (a == 3u && bb == 2u)) return 2u;
+  return 3u;
+}
+__device__ __forceinline__ float pick(const float4& v, uint32_t c) {
+  return c == 0u ? v.x : (c == 1u ? v.y : (c == 2u ? v.z : v.w));
 }
 
-// side of a FIXED pair (p0,p1) with the two bases q0 next to p0 and q1 next to p1 on the loop
-// side, per class: Turner pen | mismatch_c[p0][p1][q0][q1] + pen; CONTRAfold helix_close +
-// terminal_mismatch (+ extra: the base-pair score when the pair is the enclosed one)
 template <bool CONTRA>
-__device__ __forceinline__ void fixed_side(const TreeBatch& b, int p0, int p1, int q0, int q1, float extra,
-                                           float (&v)[4]) {
+__device__ __forceinline__ float4 fixed_side(const TreeBatch& b, int p0, int p1, int q0, int q1, float extra) {
   if (CONTRA) {
     const rnamc_fold_score_sets& f = b.params->contra;
     const float x = (f.helix_close_scores[p0][p1] + f.terminal_mismatch_scores[p0][p1][q0][q1]) + extra;
-    v[0] = v[1] = v[2] = v[3] = x;
-  } else {
-    const rnamc_turner_scores& tt = b.params->turner;
-    const float pen = augu(p0, p1) ? tt.helix_augu_end_penalty : 0.f;
-    v[0] = pen;
-    v[1] = tt.terminal_mismatch_scores_1xmany[p0][p1][q0][q1] + pen;
-    v[2] = tt.terminal_mismatch_scores_2x3[p0][p1][q0][q1] + pen;
-    v[3] = tt.terminal_mismatch_scores_interior[p0][p1][q0][q1] + pen;
+    return make_float4(x, x, x, x);
+  }
+  const rnamc_turner_scores& tt = b.params->turner;
+  const float pen = augu(p0, p1) ? tt.helix_augu_end_penalty : 0.f;
+  return make_float4(pen, tt.terminal_mismatch_scores_1xmany[p0][p1][q0][q1] + pen,
+                     tt.terminal_mismatch_scores_2x3[p0][p1][q0][q1] + pen,
+                     tt.terminal_mismatch_scores_interior[p0][p1][q0][q1] + pen);
+}
+
+template <bool CONTRA>
+__global__ void __launch_bounds__(256) k_tree_static(TreeBatch b) {
+  const TSeq q = load_tseq(b, blockIdx.y);
+  const uint32_t n = q.n, ld = q.ld;
+  const uint8_t* __restrict__ s = q.s;
+  const auto model = TModel<CONTRA>::make(b);
+  const uint64_t cells = static_cast<uint64_t>(n) * n;
+  for (uint64_t x = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; x < cells;
+       x += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const uint32_t i = static_cast<uint32_t>(x / n), j = static_cast<uint32_t>(x % n);
+    if (j <= i) continue;
+    const uint32_t d = j - i;
+    const int si = s[i], sj = s[j];
+    const bool act = canonical(si, sj) &&
+                     ((b.allows_short_hairpins && CONTRA) || d + 1 >= RNAMC_MIN_SPAN_HAIRPIN_CLOSE);
+    if (!act) continue;  // (the slots were filled with -inf / 0 by k_tree_init)
+    const size_t o = static_cast<size_t>(i) * ld + j;
+    q.m[T_HP][o] = (!CONTRA || d - 1 <= RNAMC_MAX_LOOP_LEN) ? model.hairpin(s, n, i, j) : kNegInf;
+    q.m[T_MBC][o] = model.mbclose(s, n, i, j);
+    q.m[T_ACCS][o] = model.accessible(s, n, i, j);
+    reinterpret_cast<float4*>(q.m[T_CS4])[o] = fixed_side<CONTRA>(b, si, sj, s[i + 1], s[j - 1], 0.f);
+    float4 in4 = make_float4(0.f, 0.f, 0.f, 0.f);  // (a pair at either end encloses nothing)
+    if (i >= 1 && j + 1 < n)
+      in4 = fixed_side<CONTRA>(b, sj, si, s[j + 1], s[i - 1],
+                               CONTRA ? b.params->contra.basepair_scores[si][sj] : 0.f);
+    reinterpret_cast<float4*>(q.m[T_IN4])[o] = in4;
   }
 }
 
-// closing-pair block of cell (i,j): hairpin and multibranch term (both held by the caller,
-// uniform) and the <= 496 enclosed pairs (src/mccaskill_algo.rs:306-325 / 412-436);
-// wi = bases i .. i+31, wj = bases j-31 .. j
+// closing-pair block of the pair (i,j) (src/mccaskill_algo.rs:297-343 / 400-467): hairpin and
+// multibranch term (held by the caller, uniform) and the <= 496 enclosed pairs
+// (k,l) = (i+1+a, j-1-b); wi = bases i .. i+31, wj = bases j-31 .. j
 template <bool CONTRA, int TPC>
-__device__ __forceinline__ void pair_block(const TreeBatch& b, const float* __restrict__ qb_r,
-                                           uint32_t ld, Acc& acc, uint32_t i, uint32_t j, uint32_t t,
-                                           uint64_t wi, uint64_t wj, float hp, float mbt) {
-  const uint32_t d = j - i;
+__device__ __forceinline__ void pair_block(const TreeBatch& b, const TSeq& q, Acc& acc, uint32_t i,
+                                           uint32_t j, uint32_t t, float hp, float mbt,
+                                           const float4& cs4, uint64_t wi, uint64_t wj) {
+  const uint32_t d = j - i, ld = q.ld;
   acc_add(acc, t == 0u ? hp : (t == 1u ? mbt : kNegInf));
 #ifdef RNAMC_DEBUG_KNOBS
   if (b.debug & 1) return;
 #endif
   if (d < 3u) return;
-  const int ci = wb(wi, 0), cj = wb(wj, 31);
-  const int x1 = wb(wi, 1), x2 = wb(wi, 2), y1 = wb(wj, 30), y2 = wb(wj, 29);
-  float cs[4];
-  fixed_side<CONTRA>(b, ci, cj, x1, y1, 0.f, cs);
-  const float* __restrict__ tin = &b.tabs->in[CONTRA ? 1 : 0][0][0];
+  const float4* __restrict__ qx4 = reinterpret_cast<const float4*>(q.m[T_X4]);
   const float* __restrict__ tlen = &b.tabs->len[CONTRA ? 1 : 0][0];
-  const uint32_t* __restrict__ tslot = &b.tabs->slot[CONTRA ? 1 : 0][0];
+  constexpr int NP = (512 + TPC - 1) / TPC;
+  float4 g[NP];
+  float ln[NP];
+  uint32_t cls[NP];
+  // every gather of the block first (one round trip), then the sums
 #pragma unroll
-  for (uint32_t p = t; p < 512u; p += TPC) {
-    const uint32_t sl = tslot[p];
-    const float ln = tlen[p];
-    const uint32_t a = sl & 255u, bb = (sl >> 8) & 255u, cls = (sl >> 16) & 255u;
-    if ((sl >> 24) == 1u && a + bb + 3u <= d) {
-      const uint32_t k = i + 1u + a, l = j - 1u - bb;
-      const float x = qb_r[static_cast<size_t>(k) * ld + l];
-      const uint32_t idx = (static_cast<uint32_t>(wi >> (2u * a)) & 15u) |
-                           ((static_cast<uint32_t>(wj >> (60u - 2u * bb)) & 15u) << 4);
-      const float sc = (ln + sel4(cls, cs[0], cs[1], cs[2], cs[3])) + tin[cls * 256u + idx];
-      acc_add(acc, x + sc);  // (absent pair: x = -inf)
-    }
+  for (int u = 0; u < NP; u++) {
+    const uint32_t p = t + static_cast<uint32_t>(u) * TPC;
+    uint32_t a = 0, bb = 0;
+    const bool ok = p < 512u && probe_slot(p, a, bb) && !Special<CONTRA>::is(a, bb) && a + bb + 3u <= d;
+    cls[u] = slot_class(a, bb);
+    ln[u] = ok ? tlen[p] : kNegInf;
+    g[u] = ok ? qx4[static_cast<size_t>(i + 1u + a) * ld + (j - 1u - bb)] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  float sx = kNegInf;  // the lane's small explicit loop, if it has one
   if (t < Special<CONTRA>::N) {
     uint32_t a, bb;
     Special<CONTRA>::slot(t, a, bb);
     if (a + bb + 3u <= d) {
+      // (k,l) at window positions 1+a / 30-bb, their outer neighbours at a / 31-bb
       const uint32_t k = i + 1u + a, l = j - 1u - bb;
-      const float x = qb_r[static_cast<size_t>(k) * ld + l];
-      // (k,l) = bases at window positions 1+a / 30-bb; their outer neighbours a / 31-bb
-      const float sc = TModel<CONTRA>::twoloop(b, a, bb, ci, cj, x1, x2, y1, y2, wb(wi, 1u + a),
-                                               wb(wj, 30u - bb), wb(wj, 31u - bb), wb(wi, a));
-      acc_add(acc, x + sc);
+      const float x = q.m[T_QB][static_cast<size_t>(k) * ld + l];
+      const float sc = TModel<CONTRA>::twoloop(b, a, bb, wb(wi, 0), wb(wj, 31), wb(wi, 1), wb(wi, 2),
+                                               wb(wj, 30), wb(wj, 29), wb(wi, 1u + a), wb(wj, 30u - bb),
+                                               wb(wj, 31u - bb), wb(wi, a));
+      sx = x + sc;  // (absent pair: x = -inf)
     }
   }
+  // lane-local two-pass sum (one exp2 per term), merged into the accumulator once
+  float xv[NP], mx = sx;
+#pragma unroll
+  for (int u = 0; u < NP; u++) {
+    xv[u] = (pick(g[u], cls[u]) + ln[u]) + pick(cs4, cls[u]);
+    mx = vmaxf(mx, xv[u]);
+  }
+  mx = vmaxf(mx, kEmpty);
+  float sm = ex2((sx - mx) * kL2E);
+#pragma unroll
+  for (int u = 0; u < NP; u++) sm += ex2((xv[u] - mx) * kL2E);
+  acc_merge(acc, Acc{mx, sm});
 }
 
 // enclosing 2-loops of the finished pair (i,j) (574-593 / 681-700): (k,l) = (i-1-a, j+1+b)
-// closes, (i,j) is enclosed; operands {log bpp, sums_close}(k,l) in one 8-byte load
+// closes, (i,j) is enclosed; wi = bases i-31 .. i, wj = bases j .. j+31
 template <bool CONTRA, int TPC>
 __device__ __forceinline__ void outer_block(const TreeBatch& b, const TSeq& q, Acc& acc, uint32_t i,
-                                            uint32_t j, uint32_t t, float qb) {
+                                            uint32_t j, uint32_t t, float qb, const float4& in4,
+                                            uint64_t wi, uint64_t wj) {
 #ifdef RNAMC_DEBUG_KNOBS
   if (b.debug & 1) return;
 #endif
   const uint32_t n = q.n, ld = q.ld;
-  const float2* __restrict__ pq_r = reinterpret_cast<const float2*>(q.m[T_PQ]);
-  // bases i-31 .. i and j .. j+31
-  const uint64_t wi = load_win64(q.pk, static_cast<int>(i) - 31);
-  const uint64_t wj = load_win64(q.pk, static_cast<int>(j));
-  const int ai = wb(wi, 31), aj = wb(wj, 0), m3 = wb(wi, 30), m2 = wb(wj, 1);
-  float es[4];
-  fixed_side<CONTRA>(b, aj, ai, m2, m3, CONTRA ? b.params->contra.basepair_scores[ai][aj] : 0.f, es);
-  const float* __restrict__ tout = &b.tabs->out[CONTRA ? 1 : 0][0][0];
+  const float4* __restrict__ px4 = reinterpret_cast<const float4*>(q.m[T_X4]);
   const float* __restrict__ tlen = &b.tabs->len[CONTRA ? 1 : 0][0];
-  const uint32_t* __restrict__ tslot = &b.tabs->slot[CONTRA ? 1 : 0][0];
+  constexpr int NP = (512 + TPC - 1) / TPC;
+  float4 g[NP];
+  float ln[NP];
+  uint32_t cls[NP];
 #pragma unroll
-  for (uint32_t p = t; p < 512u; p += TPC) {
-    const uint32_t sl = tslot[p];
-    const float ln = tlen[p];
-    const uint32_t a = sl & 255u, bb = (sl >> 8) & 255u, cls = (sl >> 16) & 255u;
-    if ((sl >> 24) == 1u && a < i && j + 1u + bb < n) {
-      const uint32_t k = i - 1u - a, l = j + 1u + bb;
-      const float2 pq = pq_r[static_cast<size_t>(k) * ld + l];
-      const uint32_t idx = (static_cast<uint32_t>(wi >> (60u - 2u * a)) & 15u) |
-                           ((static_cast<uint32_t>(wj >> (2u * bb)) & 15u) << 4);
-      const float sc = (ln + sel4(cls, es[0], es[1], es[2], es[3])) + tout[cls * 256u + idx];
-      if (pq.y > kNegInf) acc_add(acc, ((pq.x + qb) - pq.y) + sc);
-    }
+  for (int u = 0; u < NP; u++) {
+    const uint32_t p = t + static_cast<uint32_t>(u) * TPC;
+    uint32_t a = 0, bb = 0;
+    const bool ok = p < 512u && probe_slot(p, a, bb) && !Special<CONTRA>::is(a, bb) && a < i && j + 1u + bb < n;
+    cls[u] = slot_class(a, bb);
+    ln[u] = ok ? tlen[p] : kNegInf;
+    g[u] = ok ? px4[static_cast<size_t>(i - 1u - a) * ld + (j + 1u + bb)] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  float sx = kNegInf;
   if (t < Special<CONTRA>::N) {
     uint32_t a, bb;
     Special<CONTRA>::slot(t, a, bb);
     if (a < i && j + 1u + bb < n) {
+      // closing pair at window positions 30-a / 1+bb, its inner neighbours at 31-a, 32-a / bb, bb-1
       const uint32_t k = i - 1u - a, l = j + 1u + bb;
-      const float2 pq = pq_r[static_cast<size_t>(k) * ld + l];
-      // closing pair at window positions 30-a / 1+bb; its inner neighbours 31-a, 32-a / bb, bb-1
+      const float x = q.m[T_QB][static_cast<size_t>(k) * ld + l];
+      const float pkl = q.out[tri_off(n, l - k) + k];
       const float sc = TModel<CONTRA>::twoloop(b, a, bb, wb(wi, 30u - a), wb(wj, 1u + bb), wb(wi, 31u - a),
                                                wb(wi, a >= 1u ? 32u - a : 31u), wb(wj, bb),
-                                               wb(wj, bb >= 1u ? bb - 1u : 0u), ai, aj, m2, m3);
-      if (pq.y > kNegInf) acc_add(acc, ((pq.x + qb) - pq.y) + sc);
+                                               wb(wj, bb >= 1u ? bb - 1u : 0u), wb(wi, 31), wb(wj, 0),
+                                               wb(wj, 1), wb(wi, 30));
+      if (x > kNegInf) sx = ((pkl + qb) - x) + sc;
     }
   }
+  float xv[NP], mx = sx;  // (absent pair: its slot holds -inf)
+#pragma unroll
+  for (int u = 0; u < NP; u++) {
+    xv[u] = ((pick(g[u], cls[u]) + qb) + ln[u]) + pick(in4, cls[u]);
+    mx = vmaxf(mx, xv[u]);
+  }
+  mx = vmaxf(mx, kEmpty);
+  float sm = ex2((sx - mx) * kL2E);
+#pragma unroll
+  for (int u = 0; u < NP; u++) sm += ex2((xv[u] - mx) * kL2E);
+  acc_merge(acc, Acc{mx, sm});
 }
 
 // ----------------------------------------------------------------------------
-// inside pass.  TPC threads share the cell (i, i+d): 64 (four cells per workgroup, no
-// barrier), 256 or 1024 (one cell per workgroup); the host picks by how many cells the
-// diagonal holds.  Scalars of the cell are computed by all of its threads alike (uniform
-// loads issued at the top, beside the operand streams); its first lane stores.
-template <bool CONTRA, int TPC>
-__global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside(TreeBatch b, uint32_t d) {
-  constexpr int BLOCK = TPC < 256 ? 256 : TPC;
-  __shared__ float red[BLOCK / 64][4][2];
-#ifdef RNAMC_DEBUG_KNOBS
-  if (b.debug & 4) return;
-#endif
-  const TSeq q = load_tseq(b, blockIdx.y);
-  const uint32_t n = q.n, ld = q.ld;
-  // (wave-uniform: TPC is a multiple of 64; readfirstlane lets the cell's scalar work run on
-  // the scalar unit)
-  const uint32_t i = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
-      static_cast<int>(blockIdx.x * (BLOCK / TPC) + threadIdx.x / TPC)));
-  if (i + d >= n) return;
-  const uint32_t j = i + d;
-  const uint32_t t = threadIdx.x % TPC;
-  const uint8_t* __restrict__ s = q.s;
-  const auto model = TModel<CONTRA>::make(b);
-  const float* __restrict__ qb_r = q.m[T_QB];
-  const size_t row_i = static_cast<size_t>(i) * ld, col_j = static_cast<size_t>(j) * ld;
-  // bases i .. i+31 and j-31 .. j
-  const uint64_t wi = load_win64(q.pk, static_cast<int>(i));
-  const uint64_t wj = load_win64(q.pk, static_cast<int>(j) - 31);
-  const int ci = wb(wi, 0), cj = wb(wj, 31);
-
-  bool act = canonical(ci, cj);
-  if (!(b.allows_short_hairpins && CONTRA) && d + 1 < RNAMC_MIN_SPAN_HAIRPIN_CLOSE) act = false;
-
-  // operands of the cell's scalar recurrences (uniform loads)
-  float zr_e_prev = kNegInf, zr_m_prev = kNegInf;
-  if (j >= 1) {
-    zr_e_prev = q.m[T_ZRE][col_j - ld + i];
-    if (CONTRA) zr_m_prev = q.m[T_ZRM][col_j - ld + i];
-  }
-  const float u_next = q.m[T_U][col_j + i + 1];  // (i+1 == n: the column's pad, -inf)
-  const float zs_next = (j == n - 1) ? q.zs[i + 1] : 0.f;
-  float hp = kNegInf, mbt = kNegInf, accs = 0.f;
-  if (act) {
-    if (!CONTRA || d - 1 <= RNAMC_MAX_LOOP_LEN) hp = model.hairpin(s, n, i, j);
-    if (d >= 2) mbt = q.m[T_QM][row_i + ld + (j - 1)] + model.mbclose(s, n, i, j);
-    accs = model.accessible(s, n, i, j);
-  }
-
-  Acc acc[4] = {acc_empty(), acc_empty(), acc_empty(), acc_empty()};
-  // [0] closing-pair block (297-343 / 400-467)
-  if (act) pair_block<CONTRA, TPC>(b, qb_r, ld, acc[0], i, j, t, wi, wj, hp, mbt);
-  // [1] sums_multibranch (L_c second fold): k = i+1 .. j-1, Q1(i,k-1) + Zr_mb(k,j)
-#ifdef RNAMC_DEBUG_KNOBS
-  if (!(b.debug & 2))
-#endif
-  if (d >= 2) acc_product<TPC>(acc[1], q.m[T_Q1R] + row_i + i, q.m[T_ZRM] + col_j + i + 1, d - 1, t);
-  // [2] Z(0,j): k = 1 .. j, Zr_ext(k,j) + Z(0,k-1)       (the k = 0 term is this cell's own)
-  if (i == 0 && j >= 1) acc_product<TPC>(acc[2], q.m[T_ZRE] + col_j + 1, q.zp + 1, j, t);
-  // [3] Z(i,n-1): l = i+1 .. n-2, Qa(i,l) + Z(l+1,n-1)   (l = n-1 is this cell's own)
-  if (j == n - 1 && d >= 1) acc_product<TPC>(acc[3], q.m[T_QA] + row_i + i + 1, q.zs + i + 2, d - 1, t);
-  if (!cell_reduce<4, TPC>(acc, red)) return;
-
-  const float ext_bp = CONTRA ? b.params->contra.external_score_basepair : 0.f;
-  const float ext_un = CONTRA ? b.params->contra.external_score_unpair : 0.f;
-  const float mb_bp = CONTRA ? b.params->contra.multibranch_score_basepair
-                             : b.params->turner.coeff_num_branches;
-  const float mb_un = CONTRA ? b.params->contra.multibranch_score_unpair : 0.f;
-  const bool st = t == 0u;  // the lane that stores
-  float qa = kNegInf;
-  if (act) {
-    const float qb = acc_value(acc[0]);
-    if (qb > kNegInf) {
-      qa = qb + accs;
-      if (st) {
-        q.m[T_QB][row_i + j] = qb;
-        q.m[T_QA][row_i + j] = qa;
-      }
-    }
-  }
-  // sums_rightmost_basepairs_{external,multibranch}: one step from the cell to the left
-  const float zr_e = lse2(zr_e_prev + ext_un, qa + ext_bp);
-  const float zr_m = CONTRA ? lse2(zr_m_prev + mb_un, qa + mb_bp) : zr_e + mb_bp;
-  const float u = lse2(u_next + mb_un, zr_m);
-  const float qm = acc_value(acc[1]);
-  const float q1 = lse2(u, qm);
-  if (st) {
-    q.m[T_ZRE][col_j + i] = zr_e;
-    q.m[T_ZRM][col_j + i] = zr_m;
-    q.m[T_U][col_j + i] = u;
-    q.m[T_QM][row_i + j] = qm;
-    q.m[T_Q1R][row_i + j] = q1;
-    q.m[T_Q1C][col_j + i] = q1;
-  }
-  if (i == 0) {
-    // sums_external[0][j] (352-363 / 487-498)
-    Acc z = acc[2];
-    acc_add(z, zr_e);  // k = 0: Z(0,-1) = 0
-    acc_add(z, CONTRA ? ext_un * static_cast<float>(j + 1) : 0.f);
-    if (st) q.zp[j + 1] = acc_value(z);
-  }
-  if (j == n - 1) {
-    Acc z = acc[3];
-    z.m += ext_bp;            // every product term carries the pair's external_score_basepair
-    acc_add(z, qa + ext_bp);  // l = n-1: Z(n,n-1) = 0
-    acc_add(z, zs_next + ext_un);
-    if (st) q.zs[i] = acc_value(z);
-  }
-}
-
-// ----------------------------------------------------------------------------
-// Two diagonals per launch.  The sweep's cost is its NUMBER of dependent launches (each a
-// few microseconds of launch gap, operand round trips and drain), so one workgroup takes the
-// cells (i, j) and (i, j+1) of diagonals d and d+1.  What diagonal d+1 needs of diagonal d:
+// Two diagonals per launch.  The sweep's cost is its NUMBER of dependent launches and the
+// dependent round trips inside each, so one group of TPC threads takes the cells (i, j) and
+// (i, j+1) of diagonals d and d+1 (`single`: the cell (i,j) alone).  What diagonal d+1 needs of
+// diagonal d:
 //   inside : Zr(i,j) (own cell) and U(i+1,j+1), one step from U(i+2,j+1) given the
 //            closing-pair block of the neighbour (i+1,j+1), which is evaluated a second time here
 //            (sums_multibranch(i,j+1) itself does not: its k = i+1 term carries Q1(i,i) = -inf);
@@ -567,6 +538,9 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside(TreeBatch
 //            prefix, a product that shares its Q1 row with the cell's own and is evaluated here
 //            as a third stream (the k = j+1 term of Pm(i,j) carries Q1(j+1,j) = -inf, and the
 //            k = i-1 term of L_e Q1(i,i-1) = -inf: neither needs the neighbour).
+// TPC: 64 (four cells per workgroup, no barrier), 256 or 1024 threads per cell; the host picks
+// by the length of the cell's sums.  Scalars of a cell are computed by all of its threads alike
+// (wave-uniform: scalar unit); its first lane stores.
 
 // (+)_k over idx in [0, len1): a = A[idx]; acc0 += a + B0[idx] (idx < len0); acc1 += a + B1[idx]
 template <int TPC>
@@ -574,19 +548,24 @@ __device__ __forceinline__ void acc_product_2b(Acc& acc0, Acc& acc1, const float
                                                const float* __restrict__ B0,
                                                const float* __restrict__ B1, uint32_t len0,
                                                uint32_t len1, uint32_t t) {
-  for (uint32_t k = t; k < len1; k += 2u * TPC) {
-    const uint32_t k1 = k + TPC;
-    const bool v1 = k1 < len1;
-    const float a0 = A[k], a1 = v1 ? A[k1] : kNegInf;
-    const float p0 = k < len0 ? B0[k] : kNegInf, p1 = k1 < len0 ? B0[k1] : kNegInf;
-    const float r0 = B1[k], r1 = v1 ? B1[k1] : kNegInf;
-    acc_add2(acc0, a0 + p0, a1 + p1);
-    acc_add2(acc1, a0 + r0, a1 + r1);
+  for (uint32_t k = t; k < len1; k += 4u * TPC) {
+    float x0[4], x1[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t ku = k + static_cast<uint32_t>(u) * TPC;
+      const float a = ku < len1 ? A[ku] : kNegInf;
+      const float p = ku < len0 ? B0[ku] : kNegInf;
+      const float r = ku < len1 ? B1[ku] : kNegInf;
+      x0[u] = a + p;
+      x1[u] = a + r;
+    }
+    acc_add4(acc0, x0[0], x0[1], x0[2], x0[3]);
+    acc_add4(acc1, x1[0], x1[1], x1[2], x1[3]);
   }
 }
 
 template <bool CONTRA, int TPC>
-__global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatch b, uint32_t d) {
+__global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatch b, uint32_t d, int single) {
   constexpr int BLOCK = TPC < 256 ? 256 : TPC;
   constexpr int NA = 9;
   __shared__ float red[BLOCK / 64][NA][2];
@@ -595,67 +574,69 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
 #endif
   const TSeq q = load_tseq(b, blockIdx.y);
   const uint32_t n = q.n, ld = q.ld;
+  // (wave-uniform: TPC is a multiple of 64)
   const uint32_t i = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
       static_cast<int>(blockIdx.x * (BLOCK / TPC) + threadIdx.x / TPC)));
   if (i + d >= n) return;
   const uint32_t j = i + d, j1 = j + 1u;
-  const bool has1 = j1 < n;  // cells (i, j+1) and (i+1, j+1) exist
+  const bool has1 = !single && j1 < n;  // cells (i, j+1) and (i+1, j+1) are this launch's too
   const uint32_t t = threadIdx.x % TPC;
-  const uint8_t* __restrict__ s = q.s;
-  const auto model = TModel<CONTRA>::make(b);
-  const float* __restrict__ qb_r = q.m[T_QB];
   const size_t row_i = static_cast<size_t>(i) * ld, col_j = static_cast<size_t>(j) * ld;
-  const uint64_t wi = load_win64(q.pk, static_cast<int>(i));          // bases i .. i+31
-  const uint64_t wi1 = load_win64(q.pk, static_cast<int>(i) + 1);     // bases i+1 .. i+32
-  const uint64_t wj = load_win64(q.pk, static_cast<int>(j) - 31);     // bases j-31 .. j
-  const uint64_t wj1 = load_win64(q.pk, static_cast<int>(j) - 30);    // bases j-30 .. j+1
-  const bool span_ok = (b.allows_short_hairpins && CONTRA);
-  const bool act0 = canonical(wb(wi, 0), wb(wj, 31)) && (span_ok || d + 1 >= RNAMC_MIN_SPAN_HAIRPIN_CLOSE);
-  const bool act1 = has1 && canonical(wb(wi, 0), wb(wj1, 31)) && (span_ok || d + 2 >= RNAMC_MIN_SPAN_HAIRPIN_CLOSE);
-  const bool actn = has1 && canonical(wb(wi1, 0), wb(wj1, 31)) && (span_ok || d + 1 >= RNAMC_MIN_SPAN_HAIRPIN_CLOSE);
+  const float4* __restrict__ cs4m = reinterpret_cast<const float4*>(q.m[T_CS4]);
+  const float4* __restrict__ in4m = reinterpret_cast<const float4*>(q.m[T_IN4]);
 
-  // operands of the scalar recurrences (uniform loads, all from diagonals < d)
+  // every uniform operand, one round trip: statics of the three cells, scalar recurrences
+  const float mbc0 = sload(q.m[T_MBC] + row_i + j);
+  const float mbc1 = has1 ? sload(q.m[T_MBC] + row_i + j1) : kNegInf;
+  const float mbcn = has1 ? sload(q.m[T_MBC] + row_i + ld + j1) : kNegInf;
+  const float hp0 = sload(q.m[T_HP] + row_i + j), accs0 = sload(q.m[T_ACCS] + row_i + j);
+  const float hp1 = has1 ? sload(q.m[T_HP] + row_i + j1) : kNegInf, accs1 = has1 ? sload(q.m[T_ACCS] + row_i + j1) : 0.f;
+  const float hpn = has1 ? sload(q.m[T_HP] + row_i + ld + j1) : kNegInf, accsn = has1 ? sload(q.m[T_ACCS] + row_i + ld + j1) : 0.f;
+  const float4 cs0 = sload4(cs4m + row_i + j), in0 = sload4(in4m + row_i + j);
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 cs1 = has1 ? sload4(cs4m + row_i + j1) : zero4, in1 = has1 ? sload4(in4m + row_i + j1) : zero4;
+  const float4 csn = has1 ? sload4(cs4m + row_i + ld + j1) : zero4;
+  const float qm0 = d >= 2 ? sload(q.m[T_QM] + row_i + ld + (j - 1)) : kNegInf;              // Qm(i+1, j-1)
+  const float qm1 = (has1 && d >= 1) ? sload(q.m[T_QM] + row_i + ld + j) : kNegInf;          // Qm(i+1, j)
+  const float qmn = (has1 && d >= 2) ? sload(q.m[T_QM] + row_i + 2 * static_cast<size_t>(ld) + j) : kNegInf;  // Qm(i+2, j)
   float zr_e_prev = kNegInf, zr_m_prev = kNegInf, zr_e_prevn = kNegInf, zr_m_prevn = kNegInf;
   if (j >= 1) {
-    zr_e_prev = q.m[T_ZRE][col_j - ld + i];
-    if (CONTRA) zr_m_prev = q.m[T_ZRM][col_j - ld + i];
+    zr_e_prev = sload(q.m[T_ZRE] + col_j - ld + i);
+    if (CONTRA) zr_m_prev = sload(q.m[T_ZRM] + col_j - ld + i);
   }
-  const float u_next0 = q.m[T_U][col_j + i + 1];            // U(i+1, j)
-  float u_nextn = kNegInf;                                   // U(i+2, j+1)
+  const float u_next0 = sload(q.m[T_U] + col_j + i + 1);  // U(i+1, j)   (i+1 == n: the column's pad, -inf)
+  float u_nextn = kNegInf;                         // U(i+2, j+1)
   if (has1) {
-    zr_e_prevn = q.m[T_ZRE][col_j + i + 1];                  // Zr_ext(i+1, j)
-    if (CONTRA) zr_m_prevn = q.m[T_ZRM][col_j + i + 1];
-    u_nextn = q.m[T_U][col_j + ld + i + 2];
-  }
-  float hp0 = kNegInf, mbt0 = kNegInf, accs0 = 0.f, hp1 = kNegInf, mbt1 = kNegInf, accs1 = 0.f,
-        hpn = kNegInf, mbtn = kNegInf, accsn = 0.f;
-  if (act0) {
-    if (!CONTRA || d - 1 <= RNAMC_MAX_LOOP_LEN) hp0 = model.hairpin(s, n, i, j);
-    if (d >= 2) mbt0 = q.m[T_QM][row_i + ld + (j - 1)] + model.mbclose(s, n, i, j);
-    accs0 = model.accessible(s, n, i, j);
-  }
-  if (act1) {
-    if (!CONTRA || d <= RNAMC_MAX_LOOP_LEN) hp1 = model.hairpin(s, n, i, j1);
-    if (d >= 1) mbt1 = q.m[T_QM][row_i + ld + j] + model.mbclose(s, n, i, j1);
-    accs1 = model.accessible(s, n, i, j1);
-  }
-  if (actn) {
-    if (!CONTRA || d - 1 <= RNAMC_MAX_LOOP_LEN) hpn = model.hairpin(s, n, i + 1, j1);
-    if (d >= 2) mbtn = q.m[T_QM][row_i + 2 * static_cast<size_t>(ld) + j] + model.mbclose(s, n, i + 1, j1);
-    accsn = model.accessible(s, n, i + 1, j1);
+    zr_e_prevn = sload(q.m[T_ZRE] + col_j + i + 1);        // Zr_ext(i+1, j)
+    if (CONTRA) zr_m_prevn = sload(q.m[T_ZRM] + col_j + i + 1);
+    u_nextn = sload(q.m[T_U] + col_j + ld + i + 2);
   }
   const bool zs0 = j == n - 1, zs1 = has1 && j1 == n - 1;  // which cell sits in column n-1
-  const float zs_a = zs0 ? q.zs[i + 1] : (zs1 ? q.zs[i + 2] : 0.f);  // Z(i+1,n-1) | Z(i+2,n-1)
+  const float zs_a = zs0 ? sload(q.zs + i + 1) : (zs1 ? sload(q.zs + i + 2) : 0.f);  // Z(i+1,n-1) | Z(i+2,n-1)
+  const float zs_last = zs1 ? sload(q.zs + j + 1) : 0.f;                      // Z(n-1,n-1)
+  const float zp1 = (i == 0 && has1) ? sload(q.zp + 1) : 0.f;                 // Z(0,0)
+  const bool act0 = mbc0 > kNegInf, act1 = mbc1 > kNegInf, actn = mbcn > kNegInf;
+  // the k = i+1 term of sums_multibranch(i,j) (left out of the two-cell product below)
+  const float q1_ii = (has1 && d >= 2) ? sload(q.m[T_Q1R] + row_i + i) + sload(q.m[T_ZRM] + col_j + i + 1) : kNegInf;
+  // base windows of the small explicit loops (first wave only uses them)
+  const uint64_t wi = load_win64(q.pk, static_cast<int>(i));        // bases i .. i+31
+  const uint64_t wi1 = load_win64(q.pk, static_cast<int>(i) + 1);   // bases i+1 .. i+32
+  const uint64_t wj = load_win64(q.pk, static_cast<int>(j) - 31);   // bases j-31 .. j
+  const uint64_t wj1 = load_win64(q.pk, static_cast<int>(j) - 30);  // bases j-30 .. j+1
 
+#ifdef RNAMC_DEBUG_KNOBS
+  if (b.debug & 8) {  // timing: the launch and the uniform operand fetch alone
+    if (t == 0u && (mbc0 + mbc1 + mbcn + hp0 + hp1 + hpn + cs0.x + cs1.y + csn.z + in0.w + in1.x + qm0 + qm1 +
+                    qmn + zr_e_prev + zr_e_prevn + u_next0 + u_nextn + zs_a + q1_ii) == 12345.f)
+      q.zp[0] = 1.f;
+    return;
+  }
+#endif
   Acc acc[NA];
 #pragma unroll
   for (int x = 0; x < NA; x++) acc[x] = acc_empty();
-  // [0] [1] [2] closing-pair blocks of (i,j), (i+1,j+1), (i,j+1)
-  if (act0) pair_block<CONTRA, TPC>(b, qb_r, ld, acc[0], i, j, t, wi, wj, hp0, mbt0);
-  if (actn) pair_block<CONTRA, TPC>(b, qb_r, ld, acc[1], i + 1, j1, t, wi1, wj1, hpn, mbtn);
-  if (act1) pair_block<CONTRA, TPC>(b, qb_r, ld, acc[2], i, j1, t, wi, wj1, hp1, mbt1);
   // [3] [4] sums_multibranch of (i,j) and (i,j+1): k = i+1 .. j-1 | j, Q1(i,k-1) + Zr_mb(k,j | j+1)
-  // (the k = i+1 term of the second reads a cell of this launch: masked, it carries Q1(i,i) = -inf)
+  // (the k = i+1 term of the second reads a cell of this launch: left out, it carries Q1(i,i) = -inf)
 #ifdef RNAMC_DEBUG_KNOBS
   if (!(b.debug & 2))
 #endif
@@ -664,8 +645,7 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
       if (d >= 2)
         acc_product_2b<TPC>(acc[3], acc[4], q.m[T_Q1R] + row_i + i + 1, q.m[T_ZRM] + col_j + i + 2,
                             q.m[T_ZRM] + col_j + ld + i + 2, d - 2, d - 1, t);
-      // (k = i+1 of the first, left out above to keep both streams on the same k: one lane)
-      if (d >= 2 && t == 0u) acc_add(acc[3], q.m[T_Q1R][row_i + i] + q.m[T_ZRM][col_j + i + 1]);
+      // (k = i+1 of the first, left out to keep both streams on the same k: q1_ii, added below)
     } else if (d >= 2) {
       acc_product<TPC>(acc[3], q.m[T_Q1R] + row_i + i, q.m[T_ZRM] + col_j + i + 1, d - 1, t);
     }
@@ -674,15 +654,25 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
       if (j >= 1) acc_product<TPC>(acc[5], q.m[T_ZRE] + col_j + 1, q.zp + 1, j, t);
       if (has1 && j1 >= 2) acc_product<TPC>(acc[6], q.m[T_ZRE] + col_j + ld + 2, q.zp + 2, j1 - 1, t);
     }
-    // [7] column n-1 cell of this workgroup: l = i+1 .. n-2, Qa(i,l) + Z(l+1,n-1)
-    //     (zs0: (i,j), all l from memory; zs1: (i,j+1), l = j = n-2 is this workgroup's own cell)
-    if (zs0 && d >= 1) acc_product<TPC>(acc[7], q.m[T_QA] + row_i + i + 1, q.zs + i + 2, d - 1, t);
-    if (zs1 && d >= 1) acc_product<TPC>(acc[7], q.m[T_QA] + row_i + i + 1, q.zs + i + 2, d - 1, t);
+    // [7] column n-1 cell of this group: l = i+1 .. (zs0: n-2 | zs1: n-3), Qa(i,l) + Z(l+1,n-1)
+    //     (zs1: l = j = n-2 is this launch's own cell (i,j))
+    if ((zs0 || zs1) && d >= 1) acc_product<TPC>(acc[7], q.m[T_QA] + row_i + i + 1, q.zs + i + 2, d - 1, t);
     // [8] zs1: the neighbour (i+1,n-1)'s own sum, l = i+2 .. n-2
     if (zs1 && d >= 1)
       acc_product<TPC>(acc[8], q.m[T_QA] + row_i + ld + i + 2, q.zs + i + 3, d - 1, t);
   }
+  // [0] [1] [2] closing-pair blocks of (i,j), (i+1,j+1), (i,j+1)
+  if (act0) pair_block<CONTRA, TPC>(b, q, acc[0], i, j, t, hp0, qm0 + mbc0, cs0, wi, wj);
+  if (actn) pair_block<CONTRA, TPC>(b, q, acc[1], i + 1, j1, t, hpn, qmn + mbcn, csn, wi1, wj1);
+  if (act1) pair_block<CONTRA, TPC>(b, q, acc[2], i, j1, t, hp1, qm1 + mbc1, cs1, wi, wj1);
+  if (t == 0u) acc_add(acc[3], q1_ii);
   if (!cell_reduce<NA, TPC>(acc, red)) return;
+#ifdef RNAMC_DEBUG_KNOBS
+  if (b.debug & 16) {  // timing: no epilogue
+    if (t == 0u && acc[0].s + acc[1].s + acc[2].s + acc[3].s + acc[4].s == 12345.f) q.zp[0] = 1.f;
+    return;
+  }
+#endif
 
   const float ext_bp = CONTRA ? b.params->contra.external_score_basepair : 0.f;
   const float ext_un = CONTRA ? b.params->contra.external_score_unpair : 0.f;
@@ -690,6 +680,7 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
                              : b.params->turner.coeff_num_branches;
   const float mb_un = CONTRA ? b.params->contra.multibranch_score_unpair : 0.f;
   const bool st = t == 0u;  // the lane that stores
+  float4* __restrict__ qx4 = reinterpret_cast<float4*>(q.m[T_X4]);
   // ---- cell (i,j)
   float qa0 = kNegInf;
   if (act0) {
@@ -699,29 +690,29 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
       if (st) {
         q.m[T_QB][row_i + j] = qb;
         q.m[T_QA][row_i + j] = qa0;
+        qx4[row_i + j] = make_float4(qb + in0.x, qb + in0.y, qb + in0.z, qb + in0.w);
       }
     }
   }
   const float zr_e0 = lse2(zr_e_prev + ext_un, qa0 + ext_bp);
   const float zr_m0 = CONTRA ? lse2(zr_m_prev + mb_un, qa0 + mb_bp) : zr_e0 + mb_bp;
   const float u0 = lse2(u_next0 + mb_un, zr_m0);
-  const float qm0 = acc_value(acc[3]);
-  const float q1_0 = lse2(u0, qm0);
+  const float qmv0 = acc_value(acc[3]);
+  const float q1_0 = lse2(u0, qmv0);
   if (st) {
     q.m[T_ZRE][col_j + i] = zr_e0;
     q.m[T_ZRM][col_j + i] = zr_m0;
     q.m[T_U][col_j + i] = u0;
-    q.m[T_QM][row_i + j] = qm0;
+    q.m[T_QM][row_i + j] = qmv0;
     q.m[T_Q1R][row_i + j] = q1_0;
     q.m[T_Q1C][col_j + i] = q1_0;
   }
-  float zp_j = 0.f;  // Z(0,j)
   if (i == 0) {
+    // sums_external[0][j] (352-363 / 487-498)
     Acc z = acc[5];
     acc_add(z, zr_e0);  // k = 0: Z(0,-1) = 0
     acc_add(z, CONTRA ? ext_un * static_cast<float>(j + 1) : 0.f);
-    zp_j = acc_value(z);
-    if (st) q.zp[j + 1] = zp_j;
+    if (st) q.zp[j + 1] = acc_value(z);
   }
   if (zs0) {
     Acc z = acc[7];
@@ -731,7 +722,7 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
     if (st) q.zs[i] = acc_value(z);
   }
   if (!has1) return;
-  // ---- neighbour (i+1,j+1): closing pair -> Zr -> U, not stored (its own workgroup does)
+  // ---- neighbour (i+1,j+1): closing pair -> Zr -> U, not stored (its own group does)
   float qan = kNegInf;
   if (actn) {
     const float qb = acc_value(acc[1]);
@@ -750,26 +741,27 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
       if (st) {
         q.m[T_QB][row_i + j1] = qb;
         q.m[T_QA][row_i + j1] = qa1;
+        qx4[row_i + j1] = make_float4(qb + in1.x, qb + in1.y, qb + in1.z, qb + in1.w);
       }
     }
   }
   const float zr_e1 = lse2(zr_e0 + ext_un, qa1 + ext_bp);
   const float zr_m1 = CONTRA ? lse2(zr_m0 + mb_un, qa1 + mb_bp) : zr_e1 + mb_bp;
   const float u1 = lse2(un + mb_un, zr_m1);
-  const float qm1 = acc_value(acc[4]);
-  const float q1_1 = lse2(u1, qm1);
+  const float qmv1 = acc_value(acc[4]);
+  const float q1_1 = lse2(u1, qmv1);
   if (st) {
     q.m[T_ZRE][col_j1 + i] = zr_e1;
     q.m[T_ZRM][col_j1 + i] = zr_m1;
     q.m[T_U][col_j1 + i] = u1;
-    q.m[T_QM][row_i + j1] = qm1;
+    q.m[T_QM][row_i + j1] = qmv1;
     q.m[T_Q1R][row_i + j1] = q1_1;
     q.m[T_Q1C][col_j1 + i] = q1_1;
   }
   if (i == 0) {
     Acc z = acc[6];
-    acc_add(z, zr_e1);                // k = 0
-    acc_add(z, zr_en + q.zp[1]);      // k = 1: Zr_ext(1,j+1) + Z(0,0)
+    acc_add(z, zr_e1);        // k = 0
+    acc_add(z, zr_en + zp1);  // k = 1: Zr_ext(1,j+1) + Z(0,0)
     acc_add(z, CONTRA ? ext_un * static_cast<float>(j1 + 1) : 0.f);
     if (st) q.zp[j1 + 1] = acc_value(z);
   }
@@ -783,98 +775,10 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
     // acc[7] holds the memory terms l = i+1 .. j-1; l = j = n-2 is this launch's own cell (i,j)
     Acc z = acc[7];
     z.m += ext_bp;
-    acc_add(z, (qa0 + ext_bp) + q.zs[j + 1]);  // l = j = n-2: Z(n-1,n-1)
-    acc_add(z, qa1 + ext_bp);                  // l = n-1
+    acc_add(z, (qa0 + ext_bp) + zs_last);  // l = j = n-2: Z(n-1,n-1)
+    acc_add(z, qa1 + ext_bp);              // l = n-1
     acc_add(z, zs_n + ext_un);
     if (st) q.zs[i] = acc_value(z);
-  }
-}
-
-// ----------------------------------------------------------------------------
-// outside pass, same thread layout
-template <bool CONTRA, int TPC>
-__global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside(TreeBatch b, uint32_t d) {
-  constexpr int BLOCK = TPC < 256 ? 256 : TPC;
-  __shared__ float red[BLOCK / 64][3][2];
-#ifdef RNAMC_DEBUG_KNOBS
-  if (b.debug & 4) return;
-#endif
-  const TSeq q = load_tseq(b, blockIdx.y);
-  const uint32_t n = q.n, ld = q.ld;
-  const uint32_t i = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
-      static_cast<int>(blockIdx.x * (BLOCK / TPC) + threadIdx.x / TPC)));
-  if (i + d >= n) return;
-  const uint32_t j = i + d;
-  const uint32_t t = threadIdx.x % TPC;
-  const uint8_t* __restrict__ s = q.s;
-  const auto model = TModel<CONTRA>::make(b);
-  const float* __restrict__ qb_r = q.m[T_QB];
-  const size_t row_i = static_cast<size_t>(i) * ld, col_j = static_cast<size_t>(j) * ld;
-  const float* __restrict__ w_r = q.m[T_ZRE];   // W = (P + mbclose) - Qb, row-major
-  float* __restrict__ r_c = q.m[T_ZRM];         // R = Pm (+) Pm2, column-major
-  float* __restrict__ pm2_r = q.m[T_QM];        // probs_multibranch2, row-major
-  float* __restrict__ sp_c = q.m[T_U];          // sp_c(i,j) = (+)_{k<=i} Pm(k,j) [+ unpaired], column-major
-
-  const float qb = qb_r[row_i + j];
-  const bool paired = qb > kNegInf;  // (uniform over the cell's threads)
-  float pm2_next = kNegInf, w_next = kNegInf, sp_prev = kNegInf;
-  if (j + 1 < n) {
-    pm2_next = pm2_r[row_i + j + 1];
-    w_next = w_r[row_i + j + 1];
-  }
-  if (i >= 1) sp_prev = sp_c[col_j + i - 1];
-  float qa = kNegInf, mbc = 0.f, zpi = 0.f, zsj = 0.f, ztot = 0.f;
-  if (paired) {
-    qa = q.m[T_QA][row_i + j];
-    mbc = model.mbclose(s, n, i, j);
-    zpi = q.zp[i];
-    zsj = q.zs[j + 1];
-    ztot = q.zp[n];
-  }
-  Acc acc[3] = {acc_empty(), acc_empty(), acc_empty()};
-  // [0] probs_multibranch (L_d): k = j+1 .. n-1, W(i,k) + Q1(j+1,k-1)
-#ifdef RNAMC_DEBUG_KNOBS
-  if (!(b.debug & 2))
-#endif
-  if (j + 1 < n)
-    acc_product<TPC>(acc[0], w_r + row_i + j + 1, q.m[T_Q1R] + static_cast<size_t>(j + 1) * ld + j,
-                     n - 1 - j, t);
-  if (paired) {
-    // [1] enclosing 2-loops
-    outer_block<CONTRA, TPC>(b, q, acc[1], i, j, t, qb);
-    // [2] L_e cases one and three: k = 0 .. i-1, Q1(k+1,i-1) + R(k,j)
-#ifdef RNAMC_DEBUG_KNOBS
-    if (!(b.debug & 2))
-#endif
-    if (i >= 1) acc_product<TPC>(acc[2], q.m[T_Q1C] + static_cast<size_t>(i - 1) * ld + 1, r_c + col_j, i, t);
-  }
-  if (!cell_reduce<3, TPC>(acc, red)) return;
-
-  const bool st = t == 0u;
-  const float mb_un = CONTRA ? b.params->contra.multibranch_score_unpair : 0.f;
-  const float pm = acc_value(acc[0]);
-  const float pm2 = lse2(pm2_next + mb_un, w_next);
-  if (st) {
-    pm2_r[row_i + j] = pm2;
-    r_c[col_j + i] = lse2(pm, pm2);
-    sp_c[col_j + i] = lse2(sp_prev + mb_un, pm);
-  }
-  if (!paired) return;
-  // exterior term (561-573 / 676-680)
-  const float ext = CONTRA ? (((zpi + zsj) + qa) + b.params->contra.external_score_basepair) - ztot
-                           : ((zpi + qa) + zsj) - ztot;
-  Acc pa = acc[1];
-  acc_add(pa, ext);
-  // L_e: every term carries A = Qa + (coeff_num_branches | multibranch_score_basepair)
-  const float A = qa + (CONTRA ? b.params->contra.multibranch_score_basepair
-                               : b.params->turner.coeff_num_branches);
-  acc_add(pa, A + acc_value(acc[2]));
-  acc_add(pa, A + sp_prev);  // case two: sp_prev holds the unpaired factors of rows k < i already
-  const float lp = acc_value(pa);
-  if (st && lp > kNegInf) {
-    q.out[tri_off(n, d) + i] = lp;
-    q.m[T_ZRE][row_i + j] = (lp + mbc) - qb;
-    reinterpret_cast<float2*>(q.m[T_PQ])[row_i + j] = make_float2(lp, qb);
   }
 }
 
@@ -889,26 +793,29 @@ __device__ __forceinline__ void acc_product_3(Acc& pm0, Acc& pmn, Acc& pm1,
                                               const float* __restrict__ Qa,
                                               const float* __restrict__ Qb, uint32_t len0, bool do_n,
                                               bool do_1, uint32_t t) {
-  for (uint32_t k = t; k < len0; k += 2u * TPC) {
-    const uint32_t k1 = k + TPC;
-    const bool v1 = k1 < len0;
-    const float wi0 = Wi[k], wi1 = v1 ? Wi[k1] : kNegInf;
-    const float qa0 = Qa[k], qa1 = v1 ? Qa[k1] : kNegInf;
-    acc_add2(pm0, wi0 + qa0, wi1 + qa1);
-    if (do_n) {
-      const float wm0 = Wm[k], wm1 = v1 ? Wm[k1] : kNegInf;
-      acc_add2(pmn, wm0 + qa0, wm1 + qa1);
+  for (uint32_t k = t; k < len0; k += 4u * TPC) {
+    float x0[4], xn[4], x1[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t ku = k + static_cast<uint32_t>(u) * TPC;
+      const bool v = ku < len0;
+      const float wi = v ? Wi[ku] : kNegInf;
+      const float wm = (v && do_n) ? Wm[ku] : kNegInf;
+      const float qa = v ? Qa[ku] : kNegInf;
+      const float qb = (v && do_1 && ku >= 1u) ? Qb[ku] : kNegInf;
+      x0[u] = wi + qa;
+      xn[u] = wm + qa;
+      x1[u] = wi + qb;
     }
-    if (do_1) {
-      const float qb0 = k >= 1u ? Qb[k] : kNegInf, qb1 = v1 ? Qb[k1] : kNegInf;
-      acc_add2(pm1, wi0 + qb0, wi1 + qb1);
-    }
+    acc_add4(pm0, x0[0], x0[1], x0[2], x0[3]);
+    acc_add4(pmn, xn[0], xn[1], xn[2], xn[3]);
+    acc_add4(pm1, x1[0], x1[1], x1[2], x1[3]);
   }
 }
 
 // diagonals d+1 (cell (i,j+1)) and d (cell (i,j)) of the outside sweep
 template <bool CONTRA, int TPC>
-__global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBatch b, uint32_t d) {
+__global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBatch b, uint32_t d, int single) {
   constexpr int BLOCK = TPC < 256 ? 256 : TPC;
   constexpr int NA = 7;
   __shared__ float red[BLOCK / 64][NA][2];
@@ -921,54 +828,54 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBat
       static_cast<int>(blockIdx.x * (BLOCK / TPC) + threadIdx.x / TPC)));
   if (i + d >= n) return;
   const uint32_t j = i + d, j1 = j + 1u;
-  const bool has1 = j1 < n;
+  const bool has1 = !single && j1 < n;
   const uint32_t t = threadIdx.x % TPC;
-  const uint8_t* __restrict__ s = q.s;
-  const auto model = TModel<CONTRA>::make(b);
   const float* __restrict__ qb_r = q.m[T_QB];
   const size_t row_i = static_cast<size_t>(i) * ld, col_j = static_cast<size_t>(j) * ld;
   const float* __restrict__ w_r = q.m[T_ZRE];   // W = (P + mbclose) - Qb, row-major
   float* __restrict__ r_c = q.m[T_ZRM];         // R = Pm (+) Pm2, column-major
   float* __restrict__ pm2_r = q.m[T_QM];        // probs_multibranch2, row-major
   float* __restrict__ sp_c = q.m[T_U];          // sp_c(i,j) = (+)_{k<=i} Pm(k,j) [+ unpaired], column-major
+  const float4* __restrict__ cs4m = reinterpret_cast<const float4*>(q.m[T_CS4]);
+  const float4* __restrict__ in4m = reinterpret_cast<const float4*>(q.m[T_IN4]);
 
-  const float qb0 = qb_r[row_i + j];
-  const float qb1 = has1 ? qb_r[row_i + j1] : kNegInf;
+  // every uniform operand, one round trip (all from diagonals >= d+2 or statics)
+  const float qb0 = sload(qb_r + row_i + j);
+  const float qb1 = has1 ? sload(qb_r + row_i + j1) : kNegInf;
+  const uint32_t jt = has1 ? j1 : j;  // the upper cell of this group
+  float pm2_nextt = kNegInf, w_nextt = kNegInf, sp_prev1 = kNegInf, sp_prev2 = kNegInf;
+  if (jt + 1 < n) {
+    pm2_nextt = sload(pm2_r + row_i + jt + 1);  // Pm2(i, jt+1)
+    w_nextt = sload(w_r + row_i + jt + 1);      // W(i, jt+1)
+  }
+  if (i >= 1 && has1) sp_prev1 = sload(sp_c + col_j + ld + i - 1);  // prefix of column j+1 up to row i-1
+  if (i >= 2) sp_prev2 = sload(sp_c + col_j + i - 2);               // prefix of column j up to row i-2
+  const float ztot = sload(q.zp + n), zpi = sload(q.zp + i);
+  const float qa0 = sload(q.m[T_QA] + row_i + j), mbc0 = sload(q.m[T_MBC] + row_i + j), zsj0 = sload(q.zs + j + 1);
+  const float qa1 = has1 ? sload(q.m[T_QA] + row_i + j1) : kNegInf, mbc1 = has1 ? sload(q.m[T_MBC] + row_i + j1) : kNegInf;
+  const float zsj1 = has1 ? sload(q.zs + j1 + 1) : 0.f;
+  const float4 in0 = sload4(in4m + row_i + j), cs0 = sload4(cs4m + row_i + j);
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 in1 = has1 ? sload4(in4m + row_i + j1) : zero4, cs1 = has1 ? sload4(cs4m + row_i + j1) : zero4;
   const bool paired0 = qb0 > kNegInf, paired1 = qb1 > kNegInf;  // (uniform)
-  // operands of the scalar recurrences, all from diagonals >= d+2
-  float pm2_next1 = kNegInf, w_next1 = kNegInf, sp_prev1 = kNegInf, sp_prev2 = kNegInf;
-  if (j1 + 1 < n) {
-    pm2_next1 = pm2_r[row_i + j1 + 1];  // Pm2(i, j+2)
-    w_next1 = w_r[row_i + j1 + 1];      // W(i, j+2)
-  }
-  if (i >= 1 && has1) sp_prev1 = sp_c[col_j + ld + i - 1];  // prefix of column j+1 up to row i-1
-  if (i >= 2) sp_prev2 = sp_c[col_j + i - 2];               // prefix of column j up to row i-2
-  float qa0 = kNegInf, mbc0 = 0.f, qa1 = kNegInf, mbc1 = 0.f;
-  const float ztot = q.zp[n], zpi = q.zp[i];
-  float zsj0 = 0.f, zsj1 = 0.f;
-  if (paired0) {
-    qa0 = q.m[T_QA][row_i + j];
-    mbc0 = model.mbclose(s, n, i, j);
-    zsj0 = q.zs[j + 1];
-  }
-  if (paired1) {
-    qa1 = q.m[T_QA][row_i + j1];
-    mbc1 = model.mbclose(s, n, i, j1);
-    zsj1 = q.zs[j1 + 1];
-  }
+  // base windows of the small explicit loops (first wave only uses them)
+  const uint64_t wi = load_win64(q.pk, static_cast<int>(i) - 31);  // bases i-31 .. i
+  const uint64_t wj = load_win64(q.pk, static_cast<int>(j));       // bases j .. j+31
+  const uint64_t wj1 = load_win64(q.pk, static_cast<int>(j) + 1);  // bases j+1 .. j+32
+
   Acc acc[NA];
 #pragma unroll
   for (int x = 0; x < NA; x++) acc[x] = acc_empty();
   // [0] Pm(i,j), [1] Pm(i-1,j), [2] Pm(i,j+1): k = j+1 .. n-1 (the k = j+1 term of [0] reads
-  // W(i,j+1) of this launch next to Q1(j+1,j) = -inf: masked like [2]'s)
+  // W(i,j+1) of this launch next to Q1(j+1,j) = -inf: harmless)
 #ifdef RNAMC_DEBUG_KNOBS
   if (!(b.debug & 2))
 #endif
   {
-    if (has1 && n - 1 - j >= 2)
+    if (n - 1 - j >= 2)
       acc_product_3<TPC>(acc[0], acc[1], acc[2], w_r + row_i + j1, w_r + row_i - ld + j1,
                          q.m[T_Q1R] + static_cast<size_t>(j1) * ld + j,
-                         q.m[T_Q1R] + static_cast<size_t>(j1 + 1) * ld + j, n - 1 - j, i >= 1, true, t);
+                         q.m[T_Q1R] + static_cast<size_t>(j1 + 1) * ld + j, n - 1 - j, i >= 1, has1, t);
     // [5] [6] L_e cases one and three of (i,j) and (i,j+1): k = 0 .. i-1, Q1(k+1,i-1) + R(k,.)
     if (i >= 1 && (paired0 || paired1)) {
       if (has1)
@@ -979,8 +886,8 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBat
     }
   }
   // [3] [4] enclosing 2-loops
-  if (paired0) outer_block<CONTRA, TPC>(b, q, acc[3], i, j, t, qb0);
-  if (paired1) outer_block<CONTRA, TPC>(b, q, acc[4], i, j1, t, qb1);
+  if (paired0) outer_block<CONTRA, TPC>(b, q, acc[3], i, j, t, qb0, in0, wi, wj);
+  if (paired1) outer_block<CONTRA, TPC>(b, q, acc[4], i, j1, t, qb1, in1, wi, wj1);
   if (!cell_reduce<NA, TPC>(acc, red)) return;
 
   const bool st = t == 0u;
@@ -988,11 +895,12 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBat
   const float ext_bp = CONTRA ? b.params->contra.external_score_basepair : 0.f;
   const float abr = CONTRA ? b.params->contra.multibranch_score_basepair
                            : b.params->turner.coeff_num_branches;
+  float4* __restrict__ px4 = reinterpret_cast<float4*>(q.m[T_X4]);
   // ---- cell (i,j+1)
   float w1 = kNegInf, pm2_1 = kNegInf;
   if (has1) {
     const float pm1 = acc_value(acc[2]);
-    pm2_1 = lse2(pm2_next1 + mb_un, w_next1);
+    pm2_1 = lse2(pm2_nextt + mb_un, w_nextt);
     if (st) {
       pm2_r[row_i + j1] = pm2_1;
       r_c[col_j + ld + i] = lse2(pm1, pm2_1);
@@ -1011,12 +919,18 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBat
         if (st) {
           q.out[tri_off(n, d + 1) + i] = lp;
           q.m[T_ZRE][row_i + j1] = w1;
-          reinterpret_cast<float2*>(q.m[T_PQ])[row_i + j1] = make_float2(lp, qb1);
+          const float pq = lp - qb1;
+          px4[row_i + j1] = make_float4(pq + cs1.x, pq + cs1.y, pq + cs1.z, pq + cs1.w);
         }
       }
     }
+  } else {
+    // the single cell: Pm2 and W of its right neighbour come from memory
+    pm2_1 = pm2_nextt;
+    w1 = w_nextt;
   }
-  // ---- cell (i,j); the prefix of column j up to row i-1 needs Pm(i-1,j) of this launch
+  // ---- cell (i,j); the prefix of column j up to row i-1 needs Pm(i-1,j) (a cell of this
+  // launch when has1, recomputed here either way)
   const float pmn = acc_value(acc[1]);
   const float sp_prev0 = i >= 1 ? lse2(sp_prev2 + mb_un, pmn) : kNegInf;
   const float pm0 = acc_value(acc[0]);
@@ -1037,7 +951,8 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBat
   if (st && lp > kNegInf) {
     q.out[tri_off(n, d) + i] = lp;
     q.m[T_ZRE][row_i + j] = (lp + mbc0) - qb0;
-    reinterpret_cast<float2*>(q.m[T_PQ])[row_i + j] = make_float2(lp, qb0);
+    const float pq = lp - qb0;
+    px4[row_i + j] = make_float4(pq + cs0.x, pq + cs0.y, pq + cs0.z, pq + cs0.w);
   }
 }
 
@@ -1066,68 +981,55 @@ void launch_tree_init(const TreeBatch& b, uint32_t nseq, uint32_t max_n, bool co
   hipLaunchKernelGGL(k_tree_init, dim3(gx, nseq, 1), dim3(256), 0, st, b, contra ? 1 : 0, what);
 }
 
-// threads per cell by the number of cells of the diagonal (all sequences of the group): many
-// cells -> one wave each (four cells per workgroup, no barrier); few cells with long sums ->
-// 1024 threads each
 #define RNAMC_TREE_LAUNCH(K, C, T)                                                              \
   hipLaunchKernelGGL((K<C, T>), dim3((cells + (T < 256 ? 256 / T : 1) - 1) / (T < 256 ? 256 / T : 1), nseq, 1), \
-                     dim3(T < 256 ? 256 : T), 0, st, b, d)
-static int tree_tpc(uint64_t cells, int64_t knob) {
+                     dim3(T < 256 ? 256 : T), 0, st, b, d, two ? 0 : 1)
+// Threads per cell by the length of a cell's sums (`terms`) and the number of cells: a cell's
+// lanes walk its sums four steps per stream at a time, so `terms / (4 * threads)` dependent
+// round trips set the launch's duration; more threads per cell while the chip has room for them.
+static int tree_tpc(uint64_t cells, uint32_t terms, int64_t knob) {
   if (knob == 64 || knob == 256 || knob == 1024) return static_cast<int>(knob);
-  return cells >= 2048 ? 64 : (cells >= 192 ? 256 : 1024);
+  if (terms <= 512u) return 64;
+  if (terms <= 2048u || cells > 1024u) return 256;
+  return 1024;
+}
+
+void launch_tree_static(const TreeBatch& b, bool contra, uint32_t nseq, uint32_t max_n, hipStream_t st) {
+  const uint64_t cells = static_cast<uint64_t>(max_n) * max_n;
+  const uint32_t gx = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>((cells + 255) / 256, 4096)));
+  if (contra)
+    hipLaunchKernelGGL(k_tree_static<true>, dim3(gx, nseq, 1), dim3(256), 0, st, b);
+  else
+    hipLaunchKernelGGL(k_tree_static<false>, dim3(gx, nseq, 1), dim3(256), 0, st, b);
 }
 
 void launch_tree_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
                         int64_t tpc_knob, bool two, hipStream_t st) {
   const uint32_t cells = max_n - d;
-  const int tpc = tree_tpc(static_cast<uint64_t>(cells) * nseq, tpc_knob);
-  if (two) {
-    if (contra) {
-      if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_inside2, true, 64);
-      else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_inside2, true, 256);
-      else RNAMC_TREE_LAUNCH(k_tree_inside2, true, 1024);
-    } else {
-      if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_inside2, false, 64);
-      else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_inside2, false, 256);
-      else RNAMC_TREE_LAUNCH(k_tree_inside2, false, 1024);
-    }
-    return;
-  }
+  const int tpc = tree_tpc(static_cast<uint64_t>(cells) * nseq, d, tpc_knob);
   if (contra) {
-    if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_inside, true, 64);
-    else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_inside, true, 256);
-    else RNAMC_TREE_LAUNCH(k_tree_inside, true, 1024);
+    if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_inside2, true, 64);
+    else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_inside2, true, 256);
+    else RNAMC_TREE_LAUNCH(k_tree_inside2, true, 1024);
   } else {
-    if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_inside, false, 64);
-    else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_inside, false, 256);
-    else RNAMC_TREE_LAUNCH(k_tree_inside, false, 1024);
+    if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_inside2, false, 64);
+    else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_inside2, false, 256);
+    else RNAMC_TREE_LAUNCH(k_tree_inside2, false, 1024);
   }
 }
 
 void launch_tree_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
                          int64_t tpc_knob, bool two, hipStream_t st) {
   const uint32_t cells = max_n - d;
-  const int tpc = tree_tpc(static_cast<uint64_t>(cells) * nseq, tpc_knob);
-  if (two) {
-    if (contra) {
-      if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_outside2, true, 64);
-      else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_outside2, true, 256);
-      else RNAMC_TREE_LAUNCH(k_tree_outside2, true, 1024);
-    } else {
-      if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_outside2, false, 64);
-      else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_outside2, false, 256);
-      else RNAMC_TREE_LAUNCH(k_tree_outside2, false, 1024);
-    }
-    return;
-  }
+  const int tpc = tree_tpc(static_cast<uint64_t>(cells) * nseq, max_n - d, tpc_knob);
   if (contra) {
-    if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_outside, true, 64);
-    else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_outside, true, 256);
-    else RNAMC_TREE_LAUNCH(k_tree_outside, true, 1024);
+    if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_outside2, true, 64);
+    else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_outside2, true, 256);
+    else RNAMC_TREE_LAUNCH(k_tree_outside2, true, 1024);
   } else {
-    if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_outside, false, 64);
-    else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_outside, false, 256);
-    else RNAMC_TREE_LAUNCH(k_tree_outside, false, 1024);
+    if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_outside2, false, 64);
+    else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_outside2, false, 256);
+    else RNAMC_TREE_LAUNCH(k_tree_outside2, false, 1024);
   }
 #undef RNAMC_TREE_LAUNCH
 }

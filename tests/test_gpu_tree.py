@@ -161,13 +161,16 @@ def test_tree_kernel_variants_agree(ctx, params, contra, short):
 
 def test_tree_ragged_batch_and_lone_calls(ctx, params):
     """a ragged group (sequences leave the sweep at different diagonals) against the same
-    sequences one by one"""
+    sequences one by one: the same sums, possibly paired into launches differently (the
+    outside sweep pairs diagonals from the group's longest sequence down) — equal to rounding"""
     seqs = [O.splitmix_seq(n, 31 * n + 1) for n in (300, 299, 150, 77, 76, 5, 4, 3, 1, 222, 64)]
     for contra, short in VARIANTS:
         mb, zb = run(ctx, seqs, contra, short, 1, tree_tpc=256)
         for x, s in enumerate(seqs):
             m1, z1 = run(ctx, [s], contra, short, 1, tree_tpc=256)
-            assert np.array_equal(m1[0].packed, mb[x].packed) and z1[0] == zb[x], (contra, short, len(s))
+            same, dp = deviation(m1[0].packed, mb[x].packed)
+            assert same and dp <= 1e-5, (contra, short, len(s), dp)
+            assert abs(float(z1[0]) - float(zb[x])) <= 1e-6 * max(1.0, abs(float(zb[x])))
 
 
 def test_tree_edge_cases(ctx, params):
