@@ -476,8 +476,8 @@ def main():
                              d_out.data_ptr(), out_offsets, d_logz.data_ptr(), stream)
 
     notes = []
-    ms_main = ms_tail = ms_small = ms_head = 0.0
-    l_main = l_tail = l_small = l_head = 0
+    ms_main = ms_tail = ms_small = 0.0
+    l_main = l_tail = l_small = 0
     with_transfers = None
     pass_s = None  # measured duration of one pass (first warm-up)
 
@@ -548,7 +548,6 @@ def main():
                                           st["ms_outside_small"])
             l_main, l_tail, l_small = (st["launches_outside_main"], st["launches_outside_tail"],
                                        st["launches_outside_small"])
-            ms_head, l_head = st.get("ms_outside_head", 0.0), st.get("launches_outside_head", 0)
     steps = args.steps
     if pass_s is not None:
         # last resort: fewer timed steps than asked for, reported as such
@@ -633,12 +632,8 @@ def main():
         lf = lens.astype(np.float64)
         b_out = outside_bytes(lf, f)
         total_T = float(W.pair_cost(lf).sum())
-        # dominant kernel of the outside sweep: with the 2-loop half in a kernel of its own
-        # (LDS-staged probe windows) the "main" kernel is probs_multibranch alone
-        split_head = l_head > 0
-        b_main = outside_bytes(lf, f, "mb" if split_head else "main")
+        b_main = outside_bytes(lf, f, "main")
         b_tail = outside_bytes(lf, f, "tail")
-        b_head = outside_bytes(lf, f, "head")
         if l_main == 0:
             # nothing was large enough to split (single sequences): all roles ran in
             # k_outside<.,7>, which then is the dominant kernel
@@ -687,8 +682,7 @@ def main():
             # pass.  Its few small-launch siblings (k_outside<.,7>, < 1 % of the time) do the
             # same roles on the first diagonals; their bytes are left in
             "roofline": roof(
-                ("k_outside<.,1> (probs_multibranch, one launch per anti-diagonal)" if split_head else
-                 "k_outside<.,5> (probs_multibranch + 2-loop half of the pair probabilities, one "
+                ("k_outside<.,5> (probs_multibranch + 2-loop half of the pair probabilities, one "
                  "launch per anti-diagonal)") if l_tail else
                 ("k_outside<.,7> (outside sweep, all roles, one launch per anti-diagonal)"
                  if args.workload == "batch10k" else
@@ -724,10 +718,6 @@ def main():
                 "model_achieved": b_in_model * steps / (ms_in * 1e-3) / 1e9 if ms_in > 0 else 0.0,
             },
         })
-        if split_head:
-            res["roofline_head"] = roof(
-                "k_head_out (2-loop half of the pair probabilities, probe windows staged in LDS)",
-                b_head, ms_head, l_head, "k_outside_head")
         if args.workload != "batch10k":
             # ms per sequence: median over the timed steps (>= 5 after a warm-up)
             res["ms_per_seq"] = float(np.median(step_s)) * 1e3

@@ -318,10 +318,6 @@ typedef struct rnamc_batch_stats {
    *   small: k_outside<.,7>  all three roles in one kernel (launches too small to split) */
   uint64_t launches_outside_main, launches_outside_tail, launches_outside_small;
   double ms_outside_main, ms_outside_tail, ms_outside_small;
-  /*   head : k_head          2-loop half of the pair probabilities, operand windows staged
-   *                          through LDS (third stream); `main` is then probs_multibranch alone */
-  uint64_t launches_outside_head;
-  double ms_outside_head;
 } rnamc_batch_stats;
 int rnamc_ctx_last_stats(rnamc_ctx* ctx, rnamc_batch_stats* out);
 /* The same with the caller's idea of the struct size: copies min(out_bytes, sizeof) bytes, so a

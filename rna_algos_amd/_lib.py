@@ -50,7 +50,6 @@ class BatchStats(C.Structure):
         ("launches_outside_small", C.c_uint64),
         ("ms_outside_main", C.c_double), ("ms_outside_tail", C.c_double),
         ("ms_outside_small", C.c_double),
-        ("launches_outside_head", C.c_uint64), ("ms_outside_head", C.c_double),
     ]
 
 

@@ -65,8 +65,7 @@ struct rnamc_ctx {
   std::vector<uint64_t> group_out_floats;  // per group, when the output is staged group-local
   hipStream_t own_stream = nullptr;
   hipStream_t aux_stream = nullptr;           // pair tail of large outside launches
-  hipStream_t head_stream = nullptr;          // LDS-staged 2-loop halves (k_head), both sweeps
-  std::vector<hipEvent_t> ev_a, ev_b, ev_c;   // per-diagonal completion, ring of 16
+  std::vector<hipEvent_t> ev_a, ev_b;         // per-diagonal completion, ring of 16
   std::recursive_mutex mu;  // rnamc_fold_scores re-enters rnamc_bpp_batch
   // knobs
   // 0: every logsumexp fold in the reference's order (the parity gate); 1: order-free sums
@@ -88,10 +87,6 @@ struct rnamc_ctx {
   int64_t dual_max_diag = 1 << 30;  // ... while the diagonal has at most this many cells
   bool inside_only = false;  // set by rnamc_fold_scores around its own batch call
   int64_t fuse_inside = 1;  // Turner: fold two diagonals per launch where launches are large
-  // optional (off: measured slower): large launches run the 2-loop halves
-  // as k_head (operand windows staged through LDS) on a stream of their own; head_wmax_* =
-  // positions a workgroup's window may span (sets its LDS footprint)
-  int64_t head_lds = 0;
   // latency forms (rnamc_latency.h) for groups that cannot fill the chip: 0 never, 1 when the
   // group's longest diagonal holds at most lat_max_cells cells over all its sequences (half of
   // that under CONTRAfold), 2 always
@@ -113,7 +108,6 @@ struct rnamc_ctx {
   // CONTRAfold, eight-chains form: the sums_rightmost_basepairs folds run one launch ahead
   int64_t lat_zr_ahead = 1;
   int64_t lat_pairs = 1;   // its 2-loop blocks run one wave per listed cell (both sweeps)
-  int64_t head_wmax_in = 448, head_wmax_out = 448;
   // role mask of timing experiments (bit0 folds, 1 pair block, 2 mb, 3 pair probs); settable
   // only in builds with -DRNAMC_DEBUG_KNOBS (make DEBUG_KNOBS=1), constant 15 otherwise
   int64_t debug_roles = 15;
@@ -123,7 +117,7 @@ struct rnamc_ctx {
   std::vector<uint32_t> group_begin;  // prefix into descs
   std::vector<hipEvent_t> events;
   std::vector<hipEvent_t> kev;        // per-launch event pairs of the outside kernels (profiling)
-  std::vector<uint8_t> kev_class;     // 0 main, 1 tail, 2 small, 3 head; one per pair
+  std::vector<uint8_t> kev_class;     // 0 main, 1 tail, 2 / 3 small; one per pair
   // rnamc_fold_scores: sums_close key set of the last sequence it swept, so that the usual
   // "count, allocate, fill" pair of calls runs the device sweep once
   std::vector<uint8_t> fs_bases;
@@ -352,21 +346,12 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
     int64_t pairs_done = static_cast<int64_t>(dmin_in) - 1;  // nothing pairs below dmin_in
     int64_t heads_done = pairs_done;
     const uint32_t ring = static_cast<uint32_t>(c->ev_a.size());
-    bool head_pending = false;  // k_head launches on head_stream that `st` has not waited for
-    uint32_t head_slot = 0;
-    int head_rc = RNAMC_OK;
-    auto join_heads = [&]() {
-      if (!head_pending) return;
-      if (hipStreamWaitEvent(st, c->ev_c[head_slot], 0) != hipSuccess) head_rc = RNAMC_ERR_HIP;
-      head_pending = false;
-    };
     auto need_pairs = [&](int64_t upto) {  // complete the pair blocks of diagonals <= upto
       upto = std::min<int64_t>(upto, static_cast<int64_t>(gmax) - 1);
       while (pairs_done < upto) {
         const uint32_t D = static_cast<uint32_t>(pairs_done + 1);
         if (static_cast<int64_t>(D) <= heads_done) {
           const uint32_t nd = static_cast<uint32_t>(std::min<int64_t>(heads_done, upto)) - D + 1;
-          join_heads();  // the parked early parts come from the other stream
           if (do_pair) {
             launch_pair_tail(b, contra, D, nd, gmax, active(D), block, st);
             c->stats.launches_inside++;
@@ -479,27 +464,7 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
           launch_inside_zr2(b, d, gmax, active(d), block, st);
           c->stats.launches_inside++;
         }
-        const bool lds_head = head && do_pair && c->head_lds != 0;
-        if (lds_head) {
-          // early parts of the pair blocks of d+2, d+3 beside the folds, on their own stream:
-          // they need sums_close of diagonals <= d+1, complete on `st` at this point
-          head_slot = d % ring;
-          HIPCHK(hipEventRecord(c->ev_a[head_slot], st));
-          HIPCHK(hipStreamWaitEvent(c->head_stream, c->ev_a[head_slot], 0));
-          const uint32_t nd = std::min<uint32_t>(2u, gmax - (d + 2));
-          const int hrc = c->head_lds == 2
-                              ? launch_head_carry(b, contra, false, d + 2, nd, gmax, active(d + 2), c->head_stream)
-                              : launch_head(b, contra, false, d + 2, nd, gmax, active(d + 2),
-                                            static_cast<uint32_t>(c->head_wmax_in), c->head_stream);
-          if (hrc != 0) {
-            set_last_error("k_head (inside): launch configuration rejected");
-            return RNAMC_ERR_HIP;
-          }
-          HIPCHK(hipEventRecord(c->ev_c[head_slot], c->head_stream));
-          head_pending = true;
-          c->stats.launches_inside++;
-        }
-        launch_inside2(b, contra, d, gmax, active(d), block, do_sums, head && do_pair && !lds_head, st);
+        launch_inside2(b, contra, d, gmax, active(d), block, do_sums, head && do_pair, st);
         c->stats.launches_inside++;
         if (head) heads_done = std::min<int64_t>(static_cast<int64_t>(d) + 3, gmax - 1);
         d += 2;
@@ -513,8 +478,6 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
         d += 1;
       }
     }
-    join_heads();
-    if (head_rc) return head_rc;
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 1], st));
     // (rnamc_fold_scores needs the sums_close key set only: no outside sweep; the output
     // triangle then holds -1 / expf of stale log-probabilities and is not looked at)
@@ -549,7 +512,6 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
         (void)hipEventRecord(c->kev[2 * x + 1], s);
         c->kev_class.push_back(cls);
       };
-      bool tri = false;  // the previous diagonal ran as three kernels (k_head on head_stream)
       if (lat) {
         // latency-form group: {probs_multibranch, multibranch half of the pair probabilities}
         // of diagonal d on `st` (k_outside_lat) beside the 2-loop half of diagonal d-1 on
@@ -609,37 +571,28 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
         const bool want_dual = c->dual_outside != 0 && d < gmax &&
                                gmax - d <= static_cast<uint64_t>(c->dual_max_diag) &&
                                static_cast<uint64_t>(gmax - d) * na >= c->dual_min_cells;
-        const bool lds_head = want_dual && c->head_lds != 0;
         if (!want_dual) {
-          if (dual) {  // back to one stream: wait for the other kernels of d+1
+          if (dual) {  // back to one stream: wait for the other kernel of d+1
             HIPCHK(hipStreamWaitEvent(st, c->ev_b[(d + 1) % ring], 0));
-            if (tri) HIPCHK(hipStreamWaitEvent(st, c->ev_c[(d + 1) % ring], 0));
-            dual = tri = false;
+            dual = false;
           }
           timed(2, st, [&]() {
             launch_outside(b, contra, d, gmax, na, block, r_mb, r_tail, head && r_head, 7, st);
           });
           c->stats.launches_outside++;
         } else {
-          // every kernel of diagonal d needs every kernel of diagonal d+1
-          hipEvent_t ea = c->ev_a[d % ring], eb = c->ev_b[d % ring], ec = c->ev_c[d % ring];
+          // both kernels of diagonal d need both kernels of diagonal d+1
+          hipEvent_t ea = c->ev_a[d % ring], eb = c->ev_b[d % ring];
           const uint32_t pv = (d + 1) % ring;
           if (!dual) {
-            // first multi-kernel diagonal: everything so far is on `st`
+            // first two-kernel diagonal: everything so far is on `st`
             HIPCHK(hipEventRecord(c->ev_a[pv], st));
           } else {
             HIPCHK(hipStreamWaitEvent(st, c->ev_b[pv], 0));
-            if (tri) HIPCHK(hipStreamWaitEvent(st, c->ev_c[pv], 0));
           }
           HIPCHK(hipStreamWaitEvent(c->aux_stream, c->ev_a[pv], 0));
-          if (tri) HIPCHK(hipStreamWaitEvent(c->aux_stream, c->ev_c[pv], 0));
-          if (lds_head) {
-            HIPCHK(hipStreamWaitEvent(c->head_stream, c->ev_a[pv], 0));
-            if (dual) HIPCHK(hipStreamWaitEvent(c->head_stream, c->ev_b[pv], 0));
-          }
           timed(0, st, [&]() {
-            launch_outside(b, contra, d, gmax, na, block, r_mb, false, head && r_head && !lds_head,
-                           lds_head ? 1 : 5, st);
+            launch_outside(b, contra, d, gmax, na, block, r_mb, false, head && r_head, 5, st);
           });
           HIPCHK(hipEventRecord(ea, st));
           timed(1, c->aux_stream, [&]() {
@@ -647,29 +600,10 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
           });
           HIPCHK(hipEventRecord(eb, c->aux_stream));
           c->stats.launches_outside += 2;
-          if (lds_head) {
-            int hrc = 0;
-            if (head && r_head) {
-              timed(3, c->head_stream, [&]() {
-                hrc = c->head_lds == 2
-                          ? launch_head_carry(b, contra, true, d - 1, 1, gmax, na, c->head_stream)
-                          : launch_head(b, contra, true, d - 1, 1, gmax, na,
-                                        static_cast<uint32_t>(c->head_wmax_out), c->head_stream);
-              });
-              c->stats.launches_outside++;
-            }
-            if (hrc != 0) {
-              set_last_error("k_head (outside): launch configuration rejected");
-              return RNAMC_ERR_HIP;
-            }
-            HIPCHK(hipEventRecord(ec, c->head_stream));
-          }
           dual = true;
-          tri = lds_head;
         }
       }
       if (dual) HIPCHK(hipStreamWaitEvent(st, c->ev_b[dmin_out % ring], 0));
-      if (tri) HIPCHK(hipStreamWaitEvent(st, c->ev_c[dmin_out % ring], 0));
     }
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 2], st));
     launch_finalize(b, nseq, gmax, dmin_out, st);
@@ -703,9 +637,6 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
       } else if (c->kev_class[x] == 1) {
         c->stats.ms_outside_tail += ms;
         c->stats.launches_outside_tail++;
-      } else if (c->kev_class[x] == 3) {
-        c->stats.ms_outside_head += ms;
-        c->stats.launches_outside_head++;
       } else {
         c->stats.ms_outside_small += ms;
         c->stats.launches_outside_small++;
@@ -1070,19 +1001,14 @@ int rnamc_ctx_create(const rnamc_params* params, int device, uint64_t workspace_
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     if (hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, hi) != hipSuccess)
       return fail(RNAMC_ERR_HIP);
-    // k_head workgroups are few, long and latency-bound: place them first as well
-    if (hipStreamCreateWithPriority(&c->head_stream, hipStreamNonBlocking, hi) != hipSuccess)
-      return fail(RNAMC_ERR_HIP);
   }
   for (int x = 0; x < 16; x++) {
-    hipEvent_t ea = nullptr, eb = nullptr, ec = nullptr;
+    hipEvent_t ea = nullptr, eb = nullptr;
     if (hipEventCreateWithFlags(&ea, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&eb, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ec, hipEventDisableTiming) != hipSuccess)
+        hipEventCreateWithFlags(&eb, hipEventDisableTiming) != hipSuccess)
       return fail(RNAMC_ERR_HIP);
     c->ev_a.push_back(ea);
     c->ev_b.push_back(eb);
-    c->ev_c.push_back(ec);
   }
   if (workspace_bytes) {
     int rc = ensure_ws(c, workspace_bytes / 4);
@@ -1101,8 +1027,6 @@ void rnamc_ctx_destroy(rnamc_ctx* c) {
     for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_a) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_b) (void)hipEventDestroy(e);
-    for (hipEvent_t e : c->ev_c) (void)hipEventDestroy(e);
-    if (c->head_stream) (void)hipStreamDestroy(c->head_stream);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->st_bases) (void)hipFree(c->st_bases);
@@ -1174,8 +1098,6 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     c->dual_min_cells = static_cast<uint64_t>(value);
   } else if (k == "fuse_inside") {
     c->fuse_inside = value;
-  } else if (k == "head_lds") {
-    c->head_lds = value;
   } else if (k == "latency_mode" && value >= 0 && value <= 2) {
     c->latency_mode = value;
   } else if (k == "lat_max_cells" && value >= 0) {
@@ -1194,11 +1116,6 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     c->lat_e_waves = value;
   } else if (k == "lat_pairs") {
     c->lat_pairs = value;
-  } else if ((k == "head_wmax_in" || k == "head_wmax_out") && value >= 64 && value <= 4096) {
-    // the window must fit the CU's 160 KB of LDS beside the tables
-    if (head_smem_bytes(k == "head_wmax_out", static_cast<uint32_t>(value)) > 160u * 1024u)
-      return RNAMC_ERR_INVALID_ARG;
-    (k == "head_wmax_out" ? c->head_wmax_out : c->head_wmax_in) = value;
 #ifdef RNAMC_DEBUG_KNOBS  // result-changing: timing experiments only, never in a release build
   } else if (k == "debug_roles") {
     c->debug_roles = value;

@@ -42,20 +42,10 @@ void launch_pair_tail(const DeviceBatch& b, bool contra, uint32_t d0, uint32_t n
 // true when the folds of diagonal d run in the latency form (launch too small to fill the chip)
 bool inside_is_split(uint32_t d, uint32_t max_n, uint32_t nseq);
 // roles: 7 = all three roles in one kernel; 5 = probs_multibranch + pair head; 2 = pair tail;
-// 1 = probs_multibranch alone (the pair head then runs as k_head); 4 = pair head alone
+// 4 = pair head alone
 void launch_outside(const DeviceBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
                     uint32_t block, bool do_mb, bool do_tail, bool do_head, int roles,
                     hipStream_t st);
-// 2-loop ("probe") halves with their operand windows staged through LDS (k_head): inside the
-// early part of the closing-pair blocks of diagonals d0 .. d0+nd-1, outside (nd = 1) the
-// 2-loop half of the pair probabilities of diagonal d0.  Returns a hipError_t as int.
-int launch_head(const DeviceBatch& b, bool contra, bool outside, uint32_t d0, uint32_t nd,
-                uint32_t max_n, uint32_t nseq, uint32_t wmax, hipStream_t st);
-size_t head_smem_bytes(bool outside, uint32_t wmax);
-// the same roles with carried operands: rows of probes are walked in pairs, the second row of a
-// pair reads from lane-private LDS slots what the first row fetched beside its own operands
-int launch_head_carry(const DeviceBatch& b, bool contra, bool outside, uint32_t d0, uint32_t nd,
-                      uint32_t max_n, uint32_t nseq, hipStream_t st);
 // Latency forms for groups too small to fill the chip (rnamc_latency.h): one wave per fold
 // chain.  A group that uses them uses them on EVERY diagonal (they keep W dense, and complete
 // sums_1ormore_basepairs of diagonal d-1 in the launch of diagonal d).

@@ -390,19 +390,18 @@ __device__ __forceinline__ bool listed_cell(const Seq& q, uint32_t d, uint32_t t
 // term once sums_multibranch of diagonal d-2 exists (PAIR_TAIL).  PAIR_FULL does both.
 enum PairMode { PAIR_FULL = 0, PAIR_HEAD = 1, PAIR_TAIL = 2 };
 
-// LDS image of the probe tables only in kernels that fold probes: the fold-only kernels
-// must stay small in LDS so that they fit on a CU beside k_head's large windows.
+// LDS image of the probe tables only in kernels that fold probes (the fold-only kernels keep
+// their LDS footprint small).
 struct NoProbeTabs {
   float unused;
 };
 template <bool WANT>
 using ProbeTabStore = typename std::conditional<WANT, ProbeTabs, NoProbeTabs>::type;
 
-template <bool CONTRA, int MODE, int SRC = 0>
+template <bool CONTRA, int MODE>
 __device__ __forceinline__ void inside_pair_cell(const DeviceBatch& b, const Seq& q, uint32_t d,
                                                  uint32_t i, bool valid, const LseTab* tab,
-                                                 const ProbeTabs& L, const float* win = nullptr,
-                                                 uint32_t wp = 0, uint32_t wi = 0) {
+                                                 const ProbeTabs& L) {
   const uint32_t n = q.n;
   const uint32_t j = i + d;
   const uint8_t* s = q.s;
@@ -420,7 +419,7 @@ __device__ __forceinline__ void inside_pair_cell(const DeviceBatch& b, const Seq
     // a+bb <= 30, k < j-1, l > k   <=>   a + bb <= d-3   (uniform over the diagonal)
     if (d >= 3) {
       const uint32_t lim = min(static_cast<uint32_t>(RNAMC_MAX_2LOOP_LEN), d - 3);
-      sum = probe_fold<CONTRA, false, SRC>(b, q, d, i, act, lim, sum, 0.f, tab, L, win, wp, wi);
+      sum = probe_fold<CONTRA, false>(b, q, d, i, act, lim, sum, 0.f, tab, L);
     }
     if (!act) return;
     if (MODE == PAIR_HEAD) {
@@ -1138,11 +1137,10 @@ __device__ __forceinline__ void outside_mb_cell(const DeviceBatch& b, const Seq&
 // pair probability of one cell, first half: exterior term ⊕ enclosing 2-loops
 // (559-593 / 663-700).  Needs only results of spans >= span+2, so it runs one
 // launch ahead of the second half and parks the running sum in the log-prob slot.
-template <bool CONTRA, int SRC = 0>
+template <bool CONTRA>
 __device__ __forceinline__ void outside_pair_head(const DeviceBatch& b, const Seq& q, uint32_t d,
                                                   uint32_t i, bool valid, const LseTab* tab,
-                                                  const ProbeTabs& L, const float* win = nullptr,
-                                                  uint32_t wp = 0, uint32_t wi = 0) {
+                                                  const ProbeTabs& L) {
   const uint32_t n = q.n;
   const uint32_t j = i + d;
   const uint32_t od = tri_off(n, d) + i;
@@ -1166,7 +1164,7 @@ __device__ __forceinline__ void outside_pair_head(const DeviceBatch& b, const Se
   // a + bb <= 30, k >= 0, l <= n-1; rows with d+2+a > n-1 have no diagonal left
   if (d + 2 < n) {
     const uint32_t lim = min(static_cast<uint32_t>(RNAMC_MAX_2LOOP_LEN), n - 3 - d);
-    p = probe_fold<CONTRA, true, SRC>(b, q, d, i, paired, lim, p, qb_ij, tab, L, win, wp, wi);
+    p = probe_fold<CONTRA, true>(b, q, d, i, paired, lim, p, qb_ij, tab, L);
   }
   if (paired) q.m[M_P][od] = p;
 }
@@ -1363,124 +1361,6 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-
-// ----------------------------------------------------------------------------
-// The 2-loop ("probe") halves as kernels of their own, operands staged through LDS.
-// All (a, b) with a + b = s read diagonal d-2-s (inside) / d+2+s (outside), shifted by a:
-// the 496 probes of a cell touch only 31 diagonals.  A workgroup of kHeadThreads listed
-// cells therefore copies the <= 31 windows its cells can touch into LDS once (coalesced,
-// every element fetched from HBM once per workgroup) and probes from LDS; fold order and
-// f32 expression trees are untouched.  With global gathers each probe was its own fetch
-// and was revisited 31 probes later, long after L1/L2 had been flushed by the streaming
-// roles: 2.7x the probes' algorithmic bytes, a third of the sweep's HBM traffic.
-// The window (31 x (span + 31) floats, twice that outside where the log probability rides
-// along) bounds the workgroup: kHeadThreads consecutive LISTED cells whose positions span
-// at most `wmax`; a denser or sparser stretch is handled in several rounds.
-constexpr uint32_t kHeadThreads = RNAMC_HEAD_THREADS;   // listed cells per staging round
-constexpr uint32_t kHeadBlock = 256;                    // threads: the rest only help to stage
-constexpr uint32_t kHeadSpan = RNAMC_HEAD_ROUNDS * kHeadThreads;  // listed cells per workgroup
-constexpr uint32_t kHeadRows = RNAMC_MAX_2LOOP_LEN + 1;
-constexpr uint32_t kHeadTabBytes = (sizeof(LseTab) + sizeof(ProbeTabs) + 15u) & ~15u;
-static_assert(kHeadThreads % 64 == 0 && kHeadThreads <= kHeadBlock, "whole waves of cells");
-
-template <bool CONTRA, bool OUTSIDE>
-__global__ void __launch_bounds__(kHeadBlock)
-    k_head(DeviceBatch b, uint32_t d0, uint32_t blocks_d, uint32_t nseq, uint32_t wmax) {
-  extern __shared__ __align__(16) unsigned char head_smem[];
-  LseTab* tabs = reinterpret_cast<LseTab*>(head_smem);
-  ProbeTabs& L = *reinterpret_cast<ProbeTabs*>(head_smem + sizeof(LseTab));
-  float* win = reinterpret_cast<float*>(head_smem + kHeadTabBytes);
-  const uint32_t wp = wmax + 32u;  // row pitch in elements (float inside, float2 outside)
-  const uint32_t bxr = blockIdx.x / nseq;
-  const uint32_t which = blockIdx.x - bxr * nseq;
-  const Seq q = load_seq(b, which);
-  const uint32_t n = q.n;
-  const uint32_t dp = d0 + bxr / blocks_d;
-  const uint32_t blk = bxr % blocks_d;
-  if (dp >= n) return;
-  const uint32_t cnt = q.ccnt[dp];
-  const uint32_t first = blk * kHeadSpan;
-  if (first >= cnt) return;  // uniform over the block
-  load_lse_table(tabs);
-  load_probe_tabs<CONTRA, OUTSIDE>(L, b.params);
-  const uint32_t end = min(cnt, first + kHeadSpan);
-  const uint16_t* __restrict__ list = q.cidx + tri_off(n, dp);
-  const uint32_t tid = threadIdx.x;
-  // rows of the window this diagonal uses
-  uint32_t nrows = 0;
-  if (!OUTSIDE) {
-    if (dp >= 3) nrows = min(static_cast<uint32_t>(RNAMC_MAX_2LOOP_LEN), dp - 3) + 1u;
-  } else {
-    if (dp + 2 < n) nrows = min(static_cast<uint32_t>(RNAMC_MAX_2LOOP_LEN), n - 3 - dp) + 1u;
-  }
-  const float* __restrict__ qb = q.m[M_QB];
-  const float* __restrict__ lp = q.m[M_P];
-  for (uint32_t start = first; start < end;) {
-    const uint32_t t = start + tid;
-    const bool have = tid < kHeadThreads && t < end;
-    const uint32_t i = have ? static_cast<uint32_t>(list[t]) : 0u;
-    const uint32_t p0 = static_cast<uint32_t>(list[start]);
-    const bool ok = have && (i - p0 < wmax);
-    // (the barrier also separates the previous round's LDS reads from this round's stores)
-    const uint32_t take = static_cast<uint32_t>(__syncthreads_count(ok ? 1 : 0));
-    const uint32_t span = static_cast<uint32_t>(list[start + take - 1u]) - p0 + 1u;
-    // Staging: every thread owns window columns w, w + 256, ... and copies them row by
-    // row, eight rows' loads in flight before the first store.
-    if (!OUTSIDE) {
-      // row s: offsets i+1+a, a <= s, of diagonal dp-2-s: p0+1 .. p0+span+s
-      const uint32_t width = span + nrows - 1u;  // widest row
-      for (uint32_t w = tid; w < width; w += kHeadBlock) {
-        for (uint32_t s0 = 0; s0 < nrows; s0 += 8) {
-          float v[8];
-#pragma unroll
-          for (uint32_t u = 0; u < 8; u++) {
-            const uint32_t s = min(s0 + u, nrows - 1u);
-            v[u] = qb[tri_off(n, dp - 2u - s) + p0 + 1u + w];
-          }
-#pragma unroll
-          for (uint32_t u = 0; u < 8; u++)
-            if (s0 + u < nrows) win[(s0 + u) * wp + w] = v[u];
-        }
-      }
-    } else {
-      // row s: offsets i-1-a, a <= s, of diagonal dp+2+s: window slot w <-> offset p0-31+w,
-      // w = 30-s .. span+29; offsets below 0 (k < 0) hold -inf (the fold masks them too)
-      float2* win2 = reinterpret_cast<float2*>(win);
-      const uint32_t width = span + 30u;
-      for (uint32_t w = tid; w < width; w += kHeadBlock) {
-        const int off = static_cast<int>(p0 + w) - 31;
-        const uint32_t uoff = off >= 0 ? static_cast<uint32_t>(off) : 0u;
-        for (uint32_t s0 = 0; s0 < nrows; s0 += 8) {
-          float vp[8], vq[8];
-#pragma unroll
-          for (uint32_t u = 0; u < 8; u++) {
-            const uint32_t s = min(s0 + u, nrows - 1u);
-            const uint32_t x = tri_off(n, dp + 2u + s) + uoff;
-            vp[u] = lp[x];
-            vq[u] = qb[x];
-          }
-#pragma unroll
-          for (uint32_t u = 0; u < 8; u++)
-            if (s0 + u < nrows)
-              win2[(s0 + u) * wp + w] =
-                  off >= 0 ? make_float2(vp[u], vq[u]) : make_float2(kNegInf, kNegInf);
-        }
-      }
-    }
-    __syncthreads();
-    // waves without a cell of this round have nothing to fold
-    if ((tid & ~63u) < take) {
-      const bool mine = tid < take;
-      const uint32_t wi = mine ? i - p0 : 0u;  // idle lanes of the wave stay inside the window
-      if (!OUTSIDE) {
-        inside_pair_cell<CONTRA, PAIR_HEAD, 1>(b, q, dp, mine ? i : 0u, mine, tabs, L, win, wp, wi);
-      } else {
-        outside_pair_head<CONTRA, 1>(b, q, dp, mine ? i : 0u, mine, tabs, L, win, wp, wi);
-      }
-    }
-    start += take;
-  }
-}
 
 #include "rnamc_latency.h"
 
@@ -1740,38 +1620,6 @@ __global__ void __launch_bounds__(64) k_pair_lat(DeviceBatch b, uint32_t d, uint
   }
 }
 
-// The 2-loop halves with carried operands (probe_fold SRC 2): one lane per listed cell,
-// kCarryBlock cells per workgroup, lane-private LDS slots carry[31][kCarryBlock] (floats
-// inside, {log prob, sums_close} pairs outside) after the tables.
-template <bool CONTRA, bool OUTSIDE, uint32_t BLOCK>
-__global__ void __launch_bounds__(BLOCK)
-    k_head_carry(DeviceBatch b, uint32_t d0, uint32_t blocks_d, uint32_t nseq) {
-  extern __shared__ __align__(16) unsigned char head_smem[];
-  LseTab* tabs = reinterpret_cast<LseTab*>(head_smem);
-  ProbeTabs& L = *reinterpret_cast<ProbeTabs*>(head_smem + sizeof(LseTab));
-  float* carry = reinterpret_cast<float*>(head_smem + kHeadTabBytes);
-  const uint32_t bxr = blockIdx.x / nseq;
-  const uint32_t which = blockIdx.x - bxr * nseq;
-  const Seq q = load_seq(b, which);
-  const uint32_t n = q.n;
-  const uint32_t dp = d0 + bxr / blocks_d;
-  const uint32_t blk = bxr % blocks_d;
-  if (dp >= n) return;
-  const uint32_t cnt = q.ccnt[dp];
-  if (blk * BLOCK >= cnt) return;  // uniform over the block
-  load_lse_table(tabs);
-  load_probe_tabs<CONTRA, OUTSIDE>(L, b.params);
-  const uint32_t t = blk * BLOCK + threadIdx.x;
-  if (t - (threadIdx.x & 63u) >= cnt) return;  // wave past the list
-  uint32_t i;
-  const bool valid = listed_cell(q, dp, t, cnt, i);
-  if (!OUTSIDE) {
-    inside_pair_cell<CONTRA, PAIR_HEAD, 2>(b, q, dp, i, valid, tabs, L, carry, BLOCK, threadIdx.x);
-  } else {
-    outside_pair_head<CONTRA, 2>(b, q, dp, i, valid, tabs, L, carry, BLOCK, threadIdx.x);
-  }
-}
-
 // final map (src/mccaskill_algo.rs:608 / 721) + log partition function.  A pair is
 // in the reference's SparseProbMat iff it got a probability, i.e. iff it is in
 // sums_close and its span was visited by the outside sweep (602-604 / 715-717).
@@ -1978,73 +1826,6 @@ void launch_pair_lat(const DeviceBatch& b, bool contra, bool outside, uint32_t d
     if (outside) hipLaunchKernelGGL((k_pair_lat<false, true>), g, dim3(64), 0, st, b, d, nseq);
     else hipLaunchKernelGGL((k_pair_lat<false, false>), g, dim3(64), 0, st, b, d, nseq);
   }
-}
-
-// LDS bytes of one k_head workgroup: tables + 31 window rows of (wmax + 32) elements
-size_t head_smem_bytes(bool outside, uint32_t wmax) {
-  return kHeadTabBytes + static_cast<size_t>(kHeadRows) * (wmax + 32u) * (outside ? 8u : 4u);
-}
-
-// 2-loop half of the closing-pair blocks (inside: diagonals d0 .. d0+nd-1, parked in the
-// sums_close slot) or of the pair probabilities (outside: diagonal d0, nd = 1), operands
-// staged through LDS
-int launch_head(const DeviceBatch& b, bool contra, bool outside, uint32_t d0, uint32_t nd,
-                uint32_t max_n, uint32_t nseq, uint32_t wmax, hipStream_t st) {
-  if (d0 >= max_n || nseq == 0 || nd == 0) return 0;
-  const uint32_t bd = (max_n - d0 + kHeadSpan - 1) / kHeadSpan;
-  const dim3 g(nd * bd * nseq, 1, 1);
-  const size_t smem = head_smem_bytes(outside, wmax);
-  static bool attr_set[2][2][2] = {};  // [contra][outside][wmax class] -- set once per size
-  static size_t attr_bytes[2][2] = {};
-#define RNAMC_LAUNCH_HEAD(C, O)                                                                     \
-  do {                                                                                              \
-    if (!attr_set[C][O][0] || attr_bytes[C][O] < smem) {                                            \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head<C, O>),              \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize,                \
-                                         static_cast<int>(smem));                                   \
-      if (e != hipSuccess) return static_cast<int>(e);                                              \
-      attr_set[C][O][0] = true;                                                                     \
-      attr_bytes[C][O] = smem;                                                                      \
-    }                                                                                               \
-    hipLaunchKernelGGL((k_head<C, O>), g, dim3(kHeadBlock), smem, st, b, d0, bd, nseq, wmax);     \
-  } while (0)
-  if (contra) {
-    if (outside) RNAMC_LAUNCH_HEAD(true, true); else RNAMC_LAUNCH_HEAD(true, false);
-  } else {
-    if (outside) RNAMC_LAUNCH_HEAD(false, true); else RNAMC_LAUNCH_HEAD(false, false);
-  }
-#undef RNAMC_LAUNCH_HEAD
-  return 0;
-}
-
-// the same with carried operands (k_head_carry): every second row of probes reads LDS
-constexpr uint32_t kCarryBlockIn = 256, kCarryBlockOut = 512;
-int launch_head_carry(const DeviceBatch& b, bool contra, bool outside, uint32_t d0, uint32_t nd,
-                      uint32_t max_n, uint32_t nseq, hipStream_t st) {
-  if (d0 >= max_n || nseq == 0 || nd == 0) return 0;
-  const uint32_t block = outside ? kCarryBlockOut : kCarryBlockIn;
-  const uint32_t bd = (max_n - d0 + block - 1) / block;
-  const dim3 g(nd * bd * nseq, 1, 1);
-  const size_t smem = kHeadTabBytes + static_cast<size_t>(kHeadRows) * block * (outside ? 8u : 4u);
-  static bool attr_set[2][2] = {};
-#define RNAMC_LAUNCH_CARRY(C, O, BL)                                                                \
-  do {                                                                                              \
-    if (!attr_set[C][O]) {                                                                          \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_carry<C, O, BL>),    \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize,                \
-                                         static_cast<int>(smem));                                   \
-      if (e != hipSuccess) return static_cast<int>(e);                                              \
-      attr_set[C][O] = true;                                                                        \
-    }                                                                                               \
-    hipLaunchKernelGGL((k_head_carry<C, O, BL>), g, dim3(BL), smem, st, b, d0, bd, nseq);           \
-  } while (0)
-  if (contra) {
-    if (outside) RNAMC_LAUNCH_CARRY(true, true, kCarryBlockOut); else RNAMC_LAUNCH_CARRY(true, false, kCarryBlockIn);
-  } else {
-    if (outside) RNAMC_LAUNCH_CARRY(false, true, kCarryBlockOut); else RNAMC_LAUNCH_CARRY(false, false, kCarryBlockIn);
-  }
-#undef RNAMC_LAUNCH_CARRY
-  return 0;
 }
 
 void launch_finalize(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, uint32_t dmin_out,

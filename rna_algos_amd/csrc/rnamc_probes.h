@@ -248,29 +248,13 @@ struct ProbeFixed {
 // `act`: this lane owns a cell that takes part; lim: largest a+b with a probe on
 // this diagonal (uniform); for OUTSIDE each lane additionally needs k >= 0 and
 // l <= n-1.
-// LDSW: the operands come from a window staged in LDS by the workgroup (k_head) instead of
-// from global memory: row s of the window holds, for diagonal d-2-s (inside) / d+2+s
-// (outside), the positions the block's lanes can touch, so every element is fetched from
-// HBM once per block instead of once per probe.
-//   inside : win[s * wp + w]  = sums_close(diag d-2-s, offset p0 + 1 + w)           (float)
-//   outside: win2[s * wp + w] = {log prob, sums_close}(diag d+2+s, offset p0 - 31 + w) (float2)
-// wi = i - p0 is the lane's position inside the block's range.
-// SRC 2 ("carry"): rows are walked in pairs.  An even row a fetches, per diagonal s, the
-// operand of its own probe AND its neighbour (one 8-byte load: offsets i+1+a, i+2+a inside;
-// i-2-a, i-1-a outside), which is the operand of row a+1 on the same diagonal, and parks it in a
-// lane-private LDS slot carry[s][lane] (`win`, lane stride `wp`, lane index `wi`); the odd row
-// a+1 reads its operands there.  Every second row's global gathers disappear: the probes' HBM
-// traffic halves.
-template <bool CONTRA, bool OUTSIDE, int SRC = 0>
+template <bool CONTRA, bool OUTSIDE>
 __device__ __forceinline__ float probe_fold(const DeviceBatch& b, const Seq& q, uint32_t d,
                                             uint32_t i, bool act, uint32_t lim, float sum,
-                                            float qb_ij, const LseTab* tab, const ProbeTabs& L,
-                                            const float* win = nullptr, uint32_t wp = 0,
-                                            uint32_t wi = 0) {
+                                            float qb_ij, const LseTab* tab, const ProbeTabs& L) {
   const uint32_t n = q.n;
   const uint32_t j = i + d;
   const float* __restrict__ qb = q.m[M_QB];
-  const float* __restrict__ lp = q.m[M_P];
   const float2* __restrict__ pq = reinterpret_cast<const float2*>(q.m[M_PQ]);
   const uint32_t i4 = i * 4u;
   // windows: wa walks with a (the k side), wb walks with b (the l side)
@@ -346,60 +330,6 @@ __device__ __forceinline__ float probe_fold(const DeviceBatch& b, const Seq& q, 
   };
   auto fetch = [&](PBuf& B, uint32_t ra, uint32_t rb) {
     const uint32_t blast = lim - ra;  // last probe of the row
-    if (SRC == 2) {
-      const bool odd = (ra & 1u) != 0u;
-#pragma unroll
-      for (int u = 0; u < kPU; u++) {
-        const uint32_t bb = min(rb + static_cast<uint32_t>(u), blast);
-        const uint32_t slot = (ra + bb) * wp + wi;
-        if (!OUTSIDE) {
-          float* cs = const_cast<float*>(win);
-          if (!odd) {
-            const float* p = reinterpret_cast<const float*>(
-                reinterpret_cast<const char*>(ubase(qb, ra, bb)) + i4);
-            const float v0 = p[0], v1 = p[1];
-            B.xs[u] = v0;
-            cs[slot] = v1;
-          } else {
-            B.xs[u] = cs[slot];
-          }
-          B.ps[u] = 0.f;
-        } else {
-          float2* cs = reinterpret_cast<float2*>(const_cast<float*>(win));
-          if (!odd) {
-            const float* pq = reinterpret_cast<const float*>(
-                reinterpret_cast<const char*>(ubase(qb, ra, bb)) + i4);
-            const float* pp = reinterpret_cast<const float*>(
-                reinterpret_cast<const char*>(ubase(lp, ra, bb)) + i4);
-            B.xs[u] = pq[0];
-            B.ps[u] = pp[0];
-            cs[slot] = make_float2(pp[-1], pq[-1]);
-          } else {
-            const float2 v = cs[slot];
-            B.ps[u] = v.x;
-            B.xs[u] = v.y;
-          }
-        }
-      }
-      return;
-    }
-    if (SRC == 1) {
-      // lane address of (row ra, b = 0); successive b are one window row (wp) apart
-      const uint32_t w0 = OUTSIDE ? ra * wp + wi + 30u - ra : ra * wp + wi + ra;
-#pragma unroll
-      for (int u = 0; u < kPU; u++) {
-        const uint32_t bb = min(rb + static_cast<uint32_t>(u), blast);
-        if (OUTSIDE) {
-          const float2 v = reinterpret_cast<const float2*>(win)[w0 + bb * wp];
-          B.ps[u] = v.x;
-          B.xs[u] = v.y;
-        } else {
-          B.xs[u] = win[w0 + bb * wp];
-          B.ps[u] = 0.f;
-        }
-      }
-      return;
-    }
 #pragma unroll
     for (int u = 0; u < kPU; u++) {
       const uint32_t bb = min(rb + static_cast<uint32_t>(u), blast);

@@ -47,9 +47,6 @@ def main():
             "lat_inside": int(rng.integers(0, 4)),
             "lat_e_waves": int(rng.choice([0, 64, 2048, 1 << 20])),
             "lat_inside_waves": int(rng.choice([0, 300, 2048, 1 << 20])),
-            "head_lds": int(rng.choice([0, 0, 1, 2])),
-            "head_wmax_in": int(rng.choice([64, 200, 448])),
-            "head_wmax_out": int(rng.choice([64, 200, 448])),
         }
         for k, v in knobs.items():
             ctx.set(k, v)
