@@ -1073,7 +1073,7 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     c->summation_mode = value;
   } else if (k == "tree_two") {
     c->tree_two = value;
-  } else if (k == "tree_tpc" && (value == 0 || value == 64 || value == 256 || value == 1024)) {
+  } else if (k == "tree_tpc" && (value == 0 || value == 64 || value == 128 || value == 256 || value == 1024)) {
     c->tree_tpc = value;
   } else if (k == "group_max_seqs" && value >= 1) {
     c->group_max_seqs = std::min<int64_t>(value, 65535);

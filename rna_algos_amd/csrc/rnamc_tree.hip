@@ -157,8 +157,9 @@ __device__ __forceinline__ bool cell_reduce(Acc (&a)[NA], float (*lds)[NA][2]) {
 #pragma unroll
   for (int x = 0; x < NA; x++) a[x] = wave_reduce(a[x]);
   if (TPC == 64) return true;
-  constexpr int W = TPC / 64;
+  constexpr int W = TPC / 64;  // waves per cell group (a 256-thread block holds 256 / TPC groups)
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const uint32_t gw = wave % static_cast<uint32_t>(W), first = wave - gw;
   if (lane == 0u) {
 #pragma unroll
     for (int x = 0; x < NA; x++) {
@@ -167,10 +168,10 @@ __device__ __forceinline__ bool cell_reduce(Acc (&a)[NA], float (*lds)[NA][2]) {
     }
   }
   __syncthreads();
-  if (wave != 0u) return false;
+  if (gw != 0u) return false;
 #pragma unroll
   for (int x = 0; x < NA; x++) {
-    Acc t = lane < static_cast<uint32_t>(W) ? Acc{lds[lane][x][0], lds[lane][x][1]} : acc_empty();
+    Acc t = lane < static_cast<uint32_t>(W) ? Acc{lds[first + lane][x][0], lds[first + lane][x][1]} : acc_empty();
     a[x] = wave_reduce(t);
   }
   return true;
@@ -585,56 +586,69 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
   const float4* __restrict__ cs4m = reinterpret_cast<const float4*>(q.m[T_CS4]);
   const float4* __restrict__ in4m = reinterpret_cast<const float4*>(q.m[T_IN4]);
 
-  // every uniform operand, one round trip: statics of the three cells, scalar recurrences
-  const float mbc0 = sload(q.m[T_MBC] + row_i + j);
-  const float mbc1 = has1 ? sload(q.m[T_MBC] + row_i + j1) : kNegInf;
-  const float mbcn = has1 ? sload(q.m[T_MBC] + row_i + ld + j1) : kNegInf;
-  const float hp0 = sload(q.m[T_HP] + row_i + j), accs0 = sload(q.m[T_ACCS] + row_i + j);
-  const float hp1 = has1 ? sload(q.m[T_HP] + row_i + j1) : kNegInf, accs1 = has1 ? sload(q.m[T_ACCS] + row_i + j1) : 0.f;
-  const float hpn = has1 ? sload(q.m[T_HP] + row_i + ld + j1) : kNegInf, accsn = has1 ? sload(q.m[T_ACCS] + row_i + ld + j1) : 0.f;
-  const float4 cs0 = sload4(cs4m + row_i + j), in0 = sload4(in4m + row_i + j);
+  // Roles inside a cell's group of TPC > 64 threads: its first three waves take one
+  // closing-pair block each (eight probe slots per lane) and join the products afterwards, the
+  // others stream products from the start; the first wave alone fetches the operands of the
+  // scalar recurrences and runs the epilogue.  (TPC == 64: the one wave does everything.)
+  const uint32_t wv = TPC == 64 ? 0u : static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(t >> 6)));
+  const bool w0 = wv == 0u;
+  // (one wave: all three blocks; two waves: (i,j) and (i,j+1) in the first, the neighbour's in the second)
+  const bool do0 = w0, don = TPC == 64 || wv == 1u, do1 = TPC == 64 || wv == (TPC == 128 ? 0u : 2u);
+  const uint32_t lane = t & 63u;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 cs1 = has1 ? sload4(cs4m + row_i + j1) : zero4, in1 = has1 ? sload4(in4m + row_i + j1) : zero4;
-  const float4 csn = has1 ? sload4(cs4m + row_i + ld + j1) : zero4;
-  const float qm0 = d >= 2 ? sload(q.m[T_QM] + row_i + ld + (j - 1)) : kNegInf;              // Qm(i+1, j-1)
-  const float qm1 = (has1 && d >= 1) ? sload(q.m[T_QM] + row_i + ld + j) : kNegInf;          // Qm(i+1, j)
-  const float qmn = (has1 && d >= 2) ? sload(q.m[T_QM] + row_i + 2 * static_cast<size_t>(ld) + j) : kNegInf;  // Qm(i+2, j)
+  // every uniform operand a wave needs, one round trip (scalar unit)
+  const float mbc0 = w0 ? sload(q.m[T_MBC] + row_i + j) : kNegInf;
+  const float mbc1 = (has1 && (w0 || do1)) ? sload(q.m[T_MBC] + row_i + j1) : kNegInf;
+  const float mbcn = (has1 && (w0 || don)) ? sload(q.m[T_MBC] + row_i + ld + j1) : kNegInf;
+  const float hp0 = w0 ? sload(q.m[T_HP] + row_i + j) : kNegInf;
+  const float hp1 = (has1 && do1) ? sload(q.m[T_HP] + row_i + j1) : kNegInf;
+  const float hpn = (has1 && don) ? sload(q.m[T_HP] + row_i + ld + j1) : kNegInf;
+  const float accs0 = w0 ? sload(q.m[T_ACCS] + row_i + j) : 0.f;
+  const float accs1 = (has1 && w0) ? sload(q.m[T_ACCS] + row_i + j1) : 0.f;
+  const float accsn = (has1 && w0) ? sload(q.m[T_ACCS] + row_i + ld + j1) : 0.f;
+  const float4 cs0 = w0 ? sload4(cs4m + row_i + j) : zero4, in0 = w0 ? sload4(in4m + row_i + j) : zero4;
+  const float4 cs1 = (has1 && do1) ? sload4(cs4m + row_i + j1) : zero4;
+  const float4 in1 = (has1 && w0) ? sload4(in4m + row_i + j1) : zero4;
+  const float4 csn = (has1 && don) ? sload4(cs4m + row_i + ld + j1) : zero4;
+  const float qm0 = (w0 && d >= 2) ? sload(q.m[T_QM] + row_i + ld + (j - 1)) : kNegInf;      // Qm(i+1, j-1)
+  const float qm1 = (has1 && do1 && d >= 1) ? sload(q.m[T_QM] + row_i + ld + j) : kNegInf;   // Qm(i+1, j)
+  const float qmn = (has1 && don && d >= 2) ? sload(q.m[T_QM] + row_i + 2 * static_cast<size_t>(ld) + j) : kNegInf;  // Qm(i+2, j)
   float zr_e_prev = kNegInf, zr_m_prev = kNegInf, zr_e_prevn = kNegInf, zr_m_prevn = kNegInf;
-  if (j >= 1) {
-    zr_e_prev = sload(q.m[T_ZRE] + col_j - ld + i);
-    if (CONTRA) zr_m_prev = sload(q.m[T_ZRM] + col_j - ld + i);
-  }
-  const float u_next0 = sload(q.m[T_U] + col_j + i + 1);  // U(i+1, j)   (i+1 == n: the column's pad, -inf)
-  float u_nextn = kNegInf;                         // U(i+2, j+1)
-  if (has1) {
-    zr_e_prevn = sload(q.m[T_ZRE] + col_j + i + 1);        // Zr_ext(i+1, j)
-    if (CONTRA) zr_m_prevn = sload(q.m[T_ZRM] + col_j + i + 1);
-    u_nextn = sload(q.m[T_U] + col_j + ld + i + 2);
-  }
+  float u_next0 = kNegInf, u_nextn = kNegInf;  // U(i+1, j), U(i+2, j+1)
   const bool zs0 = j == n - 1, zs1 = has1 && j1 == n - 1;  // which cell sits in column n-1
-  const float zs_a = zs0 ? sload(q.zs + i + 1) : (zs1 ? sload(q.zs + i + 2) : 0.f);  // Z(i+1,n-1) | Z(i+2,n-1)
-  const float zs_last = zs1 ? sload(q.zs + j + 1) : 0.f;                      // Z(n-1,n-1)
-  const float zp1 = (i == 0 && has1) ? sload(q.zp + 1) : 0.f;                 // Z(0,0)
-  const bool act0 = mbc0 > kNegInf, act1 = mbc1 > kNegInf, actn = mbcn > kNegInf;
-  // the k = i+1 term of sums_multibranch(i,j) (left out of the two-cell product below)
-  const float q1_ii = (has1 && d >= 2) ? sload(q.m[T_Q1R] + row_i + i) + sload(q.m[T_ZRM] + col_j + i + 1) : kNegInf;
-  // base windows of the small explicit loops (first wave only uses them)
-  const uint64_t wi = load_win64(q.pk, static_cast<int>(i));        // bases i .. i+31
-  const uint64_t wi1 = load_win64(q.pk, static_cast<int>(i) + 1);   // bases i+1 .. i+32
-  const uint64_t wj = load_win64(q.pk, static_cast<int>(j) - 31);   // bases j-31 .. j
-  const uint64_t wj1 = load_win64(q.pk, static_cast<int>(j) - 30);  // bases j-30 .. j+1
-
-#ifdef RNAMC_DEBUG_KNOBS
-  if (b.debug & 8) {  // timing: the launch and the uniform operand fetch alone
-    if (t == 0u && (mbc0 + mbc1 + mbcn + hp0 + hp1 + hpn + cs0.x + cs1.y + csn.z + in0.w + in1.x + qm0 + qm1 +
-                    qmn + zr_e_prev + zr_e_prevn + u_next0 + u_nextn + zs_a + q1_ii) == 12345.f)
-      q.zp[0] = 1.f;
-    return;
+  float zs_a = 0.f, zs_last = 0.f, zp1 = 0.f, q1_ii = kNegInf;
+  if (w0) {
+    if (j >= 1) {
+      zr_e_prev = sload(q.m[T_ZRE] + col_j - ld + i);
+      if (CONTRA) zr_m_prev = sload(q.m[T_ZRM] + col_j - ld + i);
+    }
+    u_next0 = sload(q.m[T_U] + col_j + i + 1);  // (i+1 == n: the column's pad, -inf)
+    if (has1) {
+      zr_e_prevn = sload(q.m[T_ZRE] + col_j + i + 1);  // Zr_ext(i+1, j)
+      if (CONTRA) zr_m_prevn = sload(q.m[T_ZRM] + col_j + i + 1);
+      u_nextn = sload(q.m[T_U] + col_j + ld + i + 2);
+    }
+    zs_a = zs0 ? sload(q.zs + i + 1) : (zs1 ? sload(q.zs + i + 2) : 0.f);  // Z(i+1,n-1) | Z(i+2,n-1)
+    zs_last = zs1 ? sload(q.zs + j + 1) : 0.f;                              // Z(n-1,n-1)
+    zp1 = (i == 0 && has1) ? sload(q.zp + 1) : 0.f;                         // Z(0,0)
+    // the k = i+1 term of sums_multibranch(i,j) (left out of the two-cell product below)
+    if (has1 && d >= 2) q1_ii = sload(q.m[T_Q1R] + row_i + i) + sload(q.m[T_ZRM] + col_j + i + 1);
   }
-#endif
+  const bool act0 = mbc0 > kNegInf, act1 = mbc1 > kNegInf, actn = mbcn > kNegInf;
+
   Acc acc[NA];
 #pragma unroll
   for (int x = 0; x < NA; x++) acc[x] = acc_empty();
+  // [0] [1] [2] closing-pair blocks of (i,j), (i+1,j+1), (i,j+1): one wave each
+  if (act0 && do0)
+    pair_block<CONTRA, 64>(b, q, acc[0], i, j, lane, hp0, qm0 + mbc0, cs0,
+                           load_win64(q.pk, static_cast<int>(i)), load_win64(q.pk, static_cast<int>(j) - 31));
+  if (actn && don)
+    pair_block<CONTRA, 64>(b, q, acc[1], i + 1, j1, lane, hpn, qmn + mbcn, csn,
+                           load_win64(q.pk, static_cast<int>(i) + 1), load_win64(q.pk, static_cast<int>(j) - 30));
+  if (act1 && do1)
+    pair_block<CONTRA, 64>(b, q, acc[2], i, j1, lane, hp1, qm1 + mbc1, cs1,
+                           load_win64(q.pk, static_cast<int>(i)), load_win64(q.pk, static_cast<int>(j) - 30));
   // [3] [4] sums_multibranch of (i,j) and (i,j+1): k = i+1 .. j-1 | j, Q1(i,k-1) + Zr_mb(k,j | j+1)
   // (the k = i+1 term of the second reads a cell of this launch: left out, it carries Q1(i,i) = -inf)
 #ifdef RNAMC_DEBUG_KNOBS
@@ -661,10 +675,6 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
     if (zs1 && d >= 1)
       acc_product<TPC>(acc[8], q.m[T_QA] + row_i + ld + i + 2, q.zs + i + 3, d - 1, t);
   }
-  // [0] [1] [2] closing-pair blocks of (i,j), (i+1,j+1), (i,j+1)
-  if (act0) pair_block<CONTRA, TPC>(b, q, acc[0], i, j, t, hp0, qm0 + mbc0, cs0, wi, wj);
-  if (actn) pair_block<CONTRA, TPC>(b, q, acc[1], i + 1, j1, t, hpn, qmn + mbcn, csn, wi1, wj1);
-  if (act1) pair_block<CONTRA, TPC>(b, q, acc[2], i, j1, t, hp1, qm1 + mbc1, cs1, wi, wj1);
   if (t == 0u) acc_add(acc[3], q1_ii);
   if (!cell_reduce<NA, TPC>(acc, red)) return;
 #ifdef RNAMC_DEBUG_KNOBS
@@ -839,33 +849,53 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBat
   const float4* __restrict__ cs4m = reinterpret_cast<const float4*>(q.m[T_CS4]);
   const float4* __restrict__ in4m = reinterpret_cast<const float4*>(q.m[T_IN4]);
 
-  // every uniform operand, one round trip (all from diagonals >= d+2 or statics)
+  // roles as in the inside kernel: the group's first two waves take one block of enclosing
+  // 2-loops each, the first wave alone the scalar operands and the epilogue
+  const uint32_t wv = TPC == 64 ? 0u : static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(t >> 6)));
+  const bool w0 = wv == 0u;
+  const bool do0 = w0, do1 = TPC == 64 || wv == 1u;
+  const uint32_t lane = t & 63u;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const float qb0 = sload(qb_r + row_i + j);
   const float qb1 = has1 ? sload(qb_r + row_i + j1) : kNegInf;
   const uint32_t jt = has1 ? j1 : j;  // the upper cell of this group
   float pm2_nextt = kNegInf, w_nextt = kNegInf, sp_prev1 = kNegInf, sp_prev2 = kNegInf;
-  if (jt + 1 < n) {
-    pm2_nextt = sload(pm2_r + row_i + jt + 1);  // Pm2(i, jt+1)
-    w_nextt = sload(w_r + row_i + jt + 1);      // W(i, jt+1)
+  float ztot = 0.f, zpi = 0.f, qa0 = kNegInf, mbc0 = kNegInf, zsj0 = 0.f, qa1 = kNegInf, mbc1 = kNegInf, zsj1 = 0.f;
+  float4 cs0 = zero4, cs1 = zero4;
+  if (w0) {  // (all from diagonals >= d+2, or statics)
+    if (jt + 1 < n) {
+      pm2_nextt = sload(pm2_r + row_i + jt + 1);  // Pm2(i, jt+1)
+      w_nextt = sload(w_r + row_i + jt + 1);      // W(i, jt+1)
+    }
+    if (i >= 1 && has1) sp_prev1 = sload(sp_c + col_j + ld + i - 1);  // prefix of column j+1 up to row i-1
+    if (i >= 2) sp_prev2 = sload(sp_c + col_j + i - 2);               // prefix of column j up to row i-2
+    ztot = sload(q.zp + n);
+    zpi = sload(q.zp + i);
+    qa0 = sload(q.m[T_QA] + row_i + j);
+    mbc0 = sload(q.m[T_MBC] + row_i + j);
+    zsj0 = sload(q.zs + j + 1);
+    cs0 = sload4(cs4m + row_i + j);
+    if (has1) {
+      qa1 = sload(q.m[T_QA] + row_i + j1);
+      mbc1 = sload(q.m[T_MBC] + row_i + j1);
+      zsj1 = sload(q.zs + j1 + 1);
+      cs1 = sload4(cs4m + row_i + j1);
+    }
   }
-  if (i >= 1 && has1) sp_prev1 = sload(sp_c + col_j + ld + i - 1);  // prefix of column j+1 up to row i-1
-  if (i >= 2) sp_prev2 = sload(sp_c + col_j + i - 2);               // prefix of column j up to row i-2
-  const float ztot = sload(q.zp + n), zpi = sload(q.zp + i);
-  const float qa0 = sload(q.m[T_QA] + row_i + j), mbc0 = sload(q.m[T_MBC] + row_i + j), zsj0 = sload(q.zs + j + 1);
-  const float qa1 = has1 ? sload(q.m[T_QA] + row_i + j1) : kNegInf, mbc1 = has1 ? sload(q.m[T_MBC] + row_i + j1) : kNegInf;
-  const float zsj1 = has1 ? sload(q.zs + j1 + 1) : 0.f;
-  const float4 in0 = sload4(in4m + row_i + j), cs0 = sload4(cs4m + row_i + j);
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 in1 = has1 ? sload4(in4m + row_i + j1) : zero4, cs1 = has1 ? sload4(cs4m + row_i + j1) : zero4;
+  const float4 in0 = do0 ? sload4(in4m + row_i + j) : zero4;
+  const float4 in1 = (has1 && do1) ? sload4(in4m + row_i + j1) : zero4;
   const bool paired0 = qb0 > kNegInf, paired1 = qb1 > kNegInf;  // (uniform)
-  // base windows of the small explicit loops (first wave only uses them)
-  const uint64_t wi = load_win64(q.pk, static_cast<int>(i) - 31);  // bases i-31 .. i
-  const uint64_t wj = load_win64(q.pk, static_cast<int>(j));       // bases j .. j+31
-  const uint64_t wj1 = load_win64(q.pk, static_cast<int>(j) + 1);  // bases j+1 .. j+32
 
   Acc acc[NA];
 #pragma unroll
   for (int x = 0; x < NA; x++) acc[x] = acc_empty();
+  // [3] [4] enclosing 2-loops of (i,j) and (i,j+1): one wave each
+  if (paired0 && do0)
+    outer_block<CONTRA, 64>(b, q, acc[3], i, j, lane, qb0, in0, load_win64(q.pk, static_cast<int>(i) - 31),
+                            load_win64(q.pk, static_cast<int>(j)));
+  if (paired1 && do1)
+    outer_block<CONTRA, 64>(b, q, acc[4], i, j1, lane, qb1, in1, load_win64(q.pk, static_cast<int>(i) - 31),
+                            load_win64(q.pk, static_cast<int>(j) + 1));
   // [0] Pm(i,j), [1] Pm(i-1,j), [2] Pm(i,j+1): k = j+1 .. n-1 (the k = j+1 term of [0] reads
   // W(i,j+1) of this launch next to Q1(j+1,j) = -inf: harmless)
 #ifdef RNAMC_DEBUG_KNOBS
@@ -885,9 +915,6 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBat
         acc_product<TPC>(acc[5], q.m[T_Q1C] + static_cast<size_t>(i - 1) * ld + 1, r_c + col_j, i - 1, t);
     }
   }
-  // [3] [4] enclosing 2-loops
-  if (paired0) outer_block<CONTRA, TPC>(b, q, acc[3], i, j, t, qb0, in0, wi, wj);
-  if (paired1) outer_block<CONTRA, TPC>(b, q, acc[4], i, j1, t, qb1, in1, wi, wj1);
   if (!cell_reduce<NA, TPC>(acc, red)) return;
 
   const bool st = t == 0u;
@@ -987,10 +1014,16 @@ void launch_tree_init(const TreeBatch& b, uint32_t nseq, uint32_t max_n, bool co
 // Threads per cell by the length of a cell's sums (`terms`) and the number of cells: a cell's
 // lanes walk its sums four steps per stream at a time, so `terms / (4 * threads)` dependent
 // round trips set the launch's duration; more threads per cell while the chip has room for them.
+// ... and no more waves than the chip holds at once (the kernels take ~88 VGPRs: 5 waves per
+// SIMD, 5120 per chip): a launch whose waves need a second round pays every fixed stage of its
+// dependent chain twice (measured: 8192 waves of 256-thread groups took as long as 4096 would
+// have taken twice).
 static int tree_tpc(uint64_t cells, uint32_t terms, int64_t knob) {
-  if (knob == 64 || knob == 256 || knob == 1024) return static_cast<int>(knob);
-  if (terms <= 512u) return 64;
-  if (terms <= 2048u || cells > 1024u) return 256;
+  if (knob == 64 || knob == 128 || knob == 256 || knob == 1024) return static_cast<int>(knob);
+  constexpr uint64_t kWaves = 4800;
+  if (terms <= 512u || cells * 2u > kWaves) return 64;
+  if (cells * 4u > kWaves) return 128;
+  if (terms <= 2048u || cells * 16u > kWaves) return 256;
   return 1024;
 }
 
@@ -1009,10 +1042,12 @@ void launch_tree_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t ma
   const int tpc = tree_tpc(static_cast<uint64_t>(cells) * nseq, d, tpc_knob);
   if (contra) {
     if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_inside2, true, 64);
+    else if (tpc == 128) RNAMC_TREE_LAUNCH(k_tree_inside2, true, 128);
     else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_inside2, true, 256);
     else RNAMC_TREE_LAUNCH(k_tree_inside2, true, 1024);
   } else {
     if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_inside2, false, 64);
+    else if (tpc == 128) RNAMC_TREE_LAUNCH(k_tree_inside2, false, 128);
     else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_inside2, false, 256);
     else RNAMC_TREE_LAUNCH(k_tree_inside2, false, 1024);
   }
@@ -1024,10 +1059,12 @@ void launch_tree_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t m
   const int tpc = tree_tpc(static_cast<uint64_t>(cells) * nseq, max_n - d, tpc_knob);
   if (contra) {
     if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_outside2, true, 64);
+    else if (tpc == 128) RNAMC_TREE_LAUNCH(k_tree_outside2, true, 128);
     else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_outside2, true, 256);
     else RNAMC_TREE_LAUNCH(k_tree_outside2, true, 1024);
   } else {
     if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_outside2, false, 64);
+    else if (tpc == 128) RNAMC_TREE_LAUNCH(k_tree_outside2, false, 128);
     else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_outside2, false, 256);
     else RNAMC_TREE_LAUNCH(k_tree_outside2, false, 1024);
   }

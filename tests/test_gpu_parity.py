@@ -510,3 +510,262 @@ def test_one_context_from_many_threads(ctx, params, trnas):
     for (packed, lz), (ref, rz) in zip(got, want):
         assert_same(packed, ref)
         assert lz.view(np.uint32) == np.float32(rz).view(np.uint32)
+
+
+def test_bench_scale_first_group_golden(params):
+    """The bench's own first lock-step group at default knobs: the 1000 longest sequences of
+    the 10k batch (1870..2048 nt), so that the 64 GB workspace cap cuts the group, the
+    two-diagonal inside schedule and the multi-kernel outside sweep engage.  A
+    2048-nt member INSIDE that group is compared with the oracle's committed checksum
+    (tests/make_golden.py batch2k: ~4 min of oracle time per model), both models.  Runs
+    through the host-buffer entry (results of group g are drained while group g+1 sweeps)."""
+    from rna_algos_amd import workloads as W
+    from rna_algos_amd.mccaskill_algo import Context
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "checksums_batch2k.json")))
+    lens = W.batch_lengths(10000)
+    order = np.argsort(-lens, kind="stable")[:1000]
+    seqs = [W.synthetic_seq(int(lens[i]), (10000 << 32) + int(i)) for i in order]
+    ln = np.array([len(s) for s in seqs], dtype=np.uint64)
+    offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    np.cumsum(ln, out=offsets[1:])
+    out_offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    np.cumsum(ln * (ln + np.uint64(1)) // np.uint64(2), out=out_offsets[1:])
+    bases = np.concatenate(seqs)
+    out = np.empty(int(out_offsets[-1]), dtype=np.float32)
+    logz = np.empty(len(seqs), dtype=np.float32)
+    ctx = Context(params, device=0)
+    try:
+        for name, info in gold["cases"].items():
+            idx = int(name.split("_")[0][len("batch"):])
+            contra = name.endswith("contra")
+            x = int(np.nonzero(order == idx)[0][0])
+            assert 0 < x < 700, "the golden member must sit inside the first group"
+            out.fill(7.0)
+            ctx.bpp_batch_into(bases, offsets, contra, False, out, out_offsets, logz)
+            st = ctx.stats()
+            assert st["n_groups"] >= 2, "the workspace cap did not cut the group"
+            got = out[int(out_offsets[x]):int(out_offsets[x + 1])].copy()
+            assert int(np.float32(logz[x]).view(np.uint32)) == info["log_partition_bits"], name
+            assert int((got >= -0.5).sum()) == info["present"]
+            got[got >= 0.9999] = 1.0
+            assert hashlib.sha256(got.tobytes()).hexdigest() == info["sha256"], name
+            # every triangle was written (no slot keeps the fill value), also in the last group
+            tail = out[int(out_offsets[-2]):]
+            assert not np.any(out[::4099] == 7.0) and not np.any(tail == 7.0)
+    finally:
+        ctx.close()
+
+
+def test_long_sequence_invariants(ctx):
+    """n = 8192, beyond any oracle run: the key set is exactly the canonical pairs of span
+    >= 5, the latency forms (taken by default by a lone sequence) and the throughput forms
+    give the same bits, and the values stay probabilities up to what f32 log-domain sums of
+    magnitude ~1e4 (ulp 1e-3) allow: the reference's own fold accumulates the same rounding,
+    its range assertion (tests/tests.rs:33,38) is made on 70-90 nt sequences."""
+    from rna_algos_amd import workloads as W
+    n = 8192
+    s = W.synthetic_seq(n, n)
+    mats, logz = ctx.bpp_batch([s], False, False)
+    m = mats[0].packed
+    try:
+        ctx.set("latency_mode", 0)
+        mats2, logz2 = ctx.bpp_batch([s], False, False)
+    finally:
+        ctx.set("latency_mode", 1)
+    assert np.array_equal(m.view(np.uint32), mats2[0].packed.view(np.uint32))
+    assert np.float32(logz[0]).view(np.uint32) == np.float32(logz2[0]).view(np.uint32)
+    assert np.isfinite(logz[0])
+    off = 0
+    rowsum = np.zeros(n)
+    for d in range(n):
+        row = m[off:off + n - d]
+        a, b = s[:n - d].astype(int), s[d:].astype(int)
+        canon = ((a + b == 3) | (a + b == 5)) & (d >= 4)
+        assert np.array_equal(row >= -0.5, canon), d
+        r = np.where(canon, row.astype(np.float64), 0.0)
+        rowsum[:n - d] += r
+        rowsum[d:] += r
+        off += n - d
+    vals = m[m >= -0.5]
+    assert vals.min() >= 0.0 and vals.max() < 1.05
+    assert rowsum.max() < 1.06
+
+
+@pytest.mark.parametrize("contra,short", [(False, False), (True, False), (True, True)])
+def test_latency_forms_bit_exact(params, contra, short):
+    """Groups too small to fill the chip run the folds in their latency forms
+    (rnamc_latency.h): every chain on a group of 8 lanes, the 8 cubic pieces of ln_exp_1p
+    evaluated speculatively, a 7-instruction step when all chains of a wave take the identity
+    piece.  Forced onto a ragged batch (several sequences per launch, lengths around the
+    wave and chunk sizes) and taken by default by a lone sequence: same bits as the oracle
+    and as the throughput forms."""
+    from rna_algos_amd.mccaskill_algo import Context
+    rng = np.random.default_rng(277 + int(contra) + 2 * int(short))
+    lens = [1, 2, 4, 5, 6, 7, 8, 9, 15, 16, 17, 31, 33, 63, 64, 65, 100, 129, 200, 257, 300]
+    seqs = [rng.integers(0, 4, int(n)).astype(np.uint8) for n in lens]
+    seqs += [np.tile(np.array([2, 1], np.uint8), 40), np.zeros(50, np.uint8),
+             np.tile(np.array([2, 3, 3, 2, 1], np.uint8), 30)]
+    ctx = Context(params, device=0)
+    try:
+        ctx.set("latency_mode", 0)
+        base, logz0 = ctx.bpp_batch(seqs, contra, short)
+        ctx.set("latency_mode", 2)
+        lat, logz1 = ctx.bpp_batch(seqs, contra, short)
+        ctx.set("group_max_seqs", 5)  # several small groups
+        ctx.set("lat_inside", 1)      # ... whose inside folds run one wave per chain as well
+        ctx.set("lat_inside_waves", 1 << 20)
+        lat2, logz2 = ctx.bpp_batch(seqs, contra, short)
+        ctx.set("lat_inside_waves", 300)  # (mixed: three-lanes form first, wave form at the end)
+        ctx.set("lat_pairs", 0)           # (2-loop blocks in their lane-per-cell form)
+        lat3, logz4 = ctx.bpp_batch(seqs, contra, short)
+        ctx.set("lat_inside", 2)          # eight chains per wave, 8-lane speculative logsumexp
+        ctx.set("lat_pairs", 1)
+        ctx.set("lat_merge", 0)           # (2-loop blocks beside the chains on a second stream)
+        ctx.set("lat_zr_ahead", 0)        # (CONTRAfold: both folds of a cell in one launch)
+        lat4, logz5 = ctx.bpp_batch(seqs, contra, short)
+        ctx.set("lat_merge", 1)
+        ctx.set("lat_zr_ahead", 1)
+        ctx.set("lat_inside", 3)          # both: wave per chain below 300 chains, else eight per wave
+        ctx.set("lat_e_waves", 200)       # (and the three-lanes form above 200 waves)
+        lat5, logz6 = ctx.bpp_batch(seqs, contra, short)
+        ctx.set("lat_e_waves", 2048)
+        ctx.set("lat_inside_waves", 2048)
+        ctx.set("latency_mode", 1)    # default: a lone sequence takes the latency forms
+        one, logz3 = ctx.bpp_batch([seqs[-4]], contra, short)
+    finally:
+        ctx.close()
+    ref, ref_logz = O.bpp_batch(params.ptr, seqs, contra, short, n_threads=16)
+    for s, a, m, m2, m3, m4, m5, r in zip(seqs, base, lat, lat2, lat3, lat4, lat5, ref):
+        for got in (m, m2, m3, m4, m5):
+            assert np.array_equal(np.asarray(a.packed).view(np.uint32),
+                                  np.asarray(got.packed).view(np.uint32)), f"n={len(s)}"
+        assert_same(m.packed, r, f"n={len(s)}")
+    for lz in (logz0, logz1, logz2, logz4, logz5, logz6):
+        assert np.array_equal(np.asarray(lz).view(np.uint32), np.asarray(ref_logz).view(np.uint32))
+    assert_same(one[0].packed, ref[-4], "lone sequence")
+    assert np.float32(logz3[0]).view(np.uint32) == np.float32(ref_logz[-4]).view(np.uint32)
+
+
+@pytest.mark.parametrize("scale", [40.0, 700.0, 20000.0])
+@pytest.mark.parametrize("contra", [False, True])
+def test_latency_forms_large_magnitudes(scale, contra):
+    """The ahead-of-chain classification of rnamc_latency.h keeps a margin that grows with
+    the magnitudes of sum and terms (1 below 2^12, 4 below 2^16, 64 below 2^20, off beyond):
+    tables scaled so that the sums of a ~200-nt sequence reach each tier.  Probabilities
+    underflow to 0 or saturate at such scales, so the LOG-domain matrices are compared."""
+    from rna_algos_amd.mccaskill_algo import Context
+    from rna_algos_amd.utils import FoldScoreSets
+    P = FoldScoreSets.synthetic(7)
+    for name, (off, cnt) in P._fields.items():
+        P._buf[off:off + 4 * cnt].view(np.float32)[:] *= np.float32(scale)
+    rng = np.random.default_rng(int(scale))
+    ctx = Context(P, device=0)
+    try:
+        ctx.set("latency_mode", 2)
+        for n in (211, 97):
+            seq = rng.integers(0, 4, n).astype(np.uint8)
+            got, logz = ctx.bpp_batch([seq], contra, False)
+            # sums_close .. mbclose everywhere; probs_multibranch{,2} where the reference has an
+            # entry (the latency forms also fill cells the reference never visits or reads)
+            _, _, mats = O.bpp_dump(P.ptr, seq, contra, False)
+            iu = np.triu_indices(n)
+            for w in range(7):
+                g, r = ctx.debug_fetch(0, w, n)[iu], mats[w][iu]
+                same = (g.view(np.uint32) == r.view(np.uint32)) | (np.isnan(g) & np.isnan(r))
+                if w >= 5:
+                    same |= ~np.isfinite(r)
+                    assert np.isfinite(r).sum() > n
+                assert same.all(), f"scale={scale} n={n} matrix {w}: {(~same).sum()} entries differ"
+            ref, ref_logz = O.bpp_batch(P.ptr, [seq], contra, False, n_threads=1)
+            assert abs(float(ref_logz[0])) > scale * n / 8  # the tier this case is meant for
+            assert_same(got[0].packed, ref[0], f"scale={scale} n={n}")
+            assert np.float32(logz[0]).view(np.uint32) == np.float32(ref_logz[0]).view(np.uint32)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("contra", [False, True])
+def test_mid_size_group_default_knobs(params, contra):
+    """A ragged group of 40 sequences whose longest diagonal holds 28 000 cells, at default
+    knobs: above CONTRAfold's latency-form limit (16 384 cells: batch forms) and below Turner's
+    (32 768: latency forms, one launch per diagonal)."""
+    from rna_algos_amd.mccaskill_algo import Context
+    rng = np.random.default_rng(4040)
+    lens = np.concatenate([[700], rng.integers(150, 700, 39)])
+    seqs = [rng.integers(0, 4, int(n)).astype(np.uint8) for n in lens]
+    ctx = Context(params, device=0)
+    try:
+        got, logz = ctx.bpp_batch(seqs, contra, False)
+        assert ctx.stats()["n_groups"] == 1
+    finally:
+        ctx.close()
+    ref, ref_logz = O.bpp_batch(params.ptr, seqs, contra, False, n_threads=16)
+    for s, g, r in zip(seqs, got, ref):
+        assert_same(g.packed, r, f"n={len(s)}")
+    assert np.array_equal(np.asarray(logz).view(np.uint32), np.asarray(ref_logz).view(np.uint32))
+
+
+def test_pool_two_contexts_one_gpu(params, ctx):
+    """rnamc_bpp_batch_multi with devices = {0, 0}: two contexts (and two host threads) on one
+    GPU, small workspaces; bit-identical to the single-context result on a ragged batch, log
+    partition functions in the caller's order; one bad record fails the call with its status
+    before any device is touched, and the pool still works afterwards."""
+    from rna_algos_amd import _lib
+    from rna_algos_amd.mccaskill_algo import Pool, shard_plan
+    rng = np.random.default_rng(17)
+    lens = [5, 900, 37, 412, 411, 64, 1, 300, 299, 150, 700, 33, 650, 20, 128]
+    seqs = [rng.integers(0, 4, n).astype(np.uint8) for n in lens]
+    pool = Pool(params, devices=[0, 0], workspace_bytes=256 << 20)
+    try:
+        assert len(pool) == 2
+        plan = shard_plan(lens, 2)
+        assert set(plan.tolist()) == {0, 1}
+        for contra in (False, True):
+            mats, logz = pool.bpp_batch(seqs, contra, False)
+            ref, ref_z = ctx.bpp_batch(seqs, contra, False)
+            for s, a, b in zip(seqs, mats, ref):
+                assert np.array_equal(a.packed, b.packed), f"n={len(s)} contra={contra}"
+            assert np.array_equal(logz, ref_z)
+        # error paths: statuses of rnamc_bpp_batch, nothing computed, pool usable afterwards
+        bad = list(seqs)
+        bad[3] = np.array([0, 1, 7, 2], dtype=np.uint8)
+        with pytest.raises(_lib.RnamcError) as e:
+            pool.bpp_batch(bad, False, False)
+        assert e.value.status == _lib.ERR_INVALID_BASE
+        with pytest.raises(_lib.RnamcError) as e:
+            pool.bpp_batch(seqs[:2] + [np.zeros(0, dtype=np.uint8)], False, False)
+        assert e.value.status == _lib.ERR_EMPTY_SEQ
+        mats, logz = pool.bpp_batch(seqs[:3], False, False)
+        ref, ref_z = ctx.bpp_batch(seqs[:3], False, False)
+        assert all(np.array_equal(a.packed, b.packed) for a, b in zip(mats, ref))
+        # a knob set on the pool reaches every context: tree-order sums on both shards
+        pool.set("summation_mode", 1)
+        mt, zt = pool.bpp_batch(seqs, False, False)
+        pool.set("summation_mode", 0)
+        for a, b in zip(mt, ref_all := ctx.bpp_batch(seqs, False, False)[0]):
+            ka, kb = np.asarray(a.packed) >= -0.5, np.asarray(b.packed) >= -0.5
+            assert np.array_equal(ka, kb)
+            assert np.max(np.abs(np.asarray(a.packed)[ka] - np.asarray(b.packed)[ka]), initial=0.0) < 2e-2
+    finally:
+        pool.close()
+
+
+def test_librnamc_first_then_torch():
+    """Init order (the round-2 "No HIP GPUs are available").  Cause:
+    torch ships its own libamdhip64.so + libhsa-runtime64.so; librnamc.so needs
+    `libamdhip64.so.7`.  Loaded FIRST, librnamc pulls in /opt/rocm's runtime; torch then loads its
+    bundled pair as a SECOND HSA runtime in the process, which finds no GPU (one KFD client per
+    process).  Loaded after torch, librnamc's NEEDED entry is satisfied by torch's copy (same
+    SONAME) and there is one runtime.  rna_algos_amd._lib therefore preloads torch's bundled
+    runtime (when torch is installed) before librnamc.so, which makes either order work; this
+    test runs the bad order in a fresh process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "init_order_probe.py"), "rnamc_first"],
+                         capture_output=True, text=True, timeout=600)
+    text = out.stdout + out.stderr
+    assert "FAILED" not in text and "torch: (True, 4.0)" in text and "rnamc again:" in text, text
+    # one HIP runtime in the process
+    mapped = [ln for ln in text.splitlines() if ln.strip().startswith("mapped:")][-1]
+    assert mapped.count("libamdhip64") == 1, mapped
