@@ -368,6 +368,18 @@ int rnamc_centroid_fold(const float* bpp_packed, uint32_t n, float centroid_thre
                         uint32_t* pairs_out, uint32_t max_pairs, uint32_t* n_pairs,
                         float* expect_accuracy);
 
+/* The same fold for SEVERAL thresholds at once, the Theta(n^3) fill on ctx's GPU (the reference
+ * runs it for 18 gammas per record, src/bin/centroid_fold.rs:147-161): one anti-diagonal sweep of
+ * (max,+) reductions for all thresholds off one copy of the bpp triangle, then the traceback of
+ * every threshold on host threads.  (max,+) is order-free in f32, so the matrices, and with them
+ * pairs, push order and expect_accuracy, are bit-identical to rnamc_centroid_fold's.
+ *   pairs_out        n_thresholds blocks of max_pairs (i,j) pairs (may be NULL)
+ *   n_pairs          n_thresholds counts;  expect_accuracy  n_thresholds scores (may be NULL) */
+int rnamc_centroid_fold_multi(rnamc_ctx* ctx, const float* bpp_packed, uint32_t n,
+                              const float* centroid_thresholds, uint32_t n_thresholds,
+                              uint32_t* pairs_out, uint32_t max_pairs, uint32_t* n_pairs,
+                              float* expect_accuracy);
+
 /* ------------------------------------------------------------------------- */
 /* Durbin pair-HMM nucleotide match probabilities (SURVEY.md 8f-4;
  * reference: src/durbin_algo.rs:73-242, constants src/compiled_align_scores.rs). */

@@ -9,8 +9,8 @@ import argparse
 import os
 import sys
 
-from ..centroid_fold import MAX_POW_2, MIN_POW_2, centroid_fold, get_fold_str
-from ..mccaskill_algo import mccaskill_algo_batch
+from ..centroid_fold import MAX_POW_2, MIN_POW_2, centroid_fold, centroid_fold_multi, get_fold_str
+from ..mccaskill_algo import Context, mccaskill_algo_batch
 from ..utils import FoldScoreSets, NoTablesError, read_fasta, set_default_tables
 from .mccaskill_algo import fmt_f32
 
@@ -55,9 +55,21 @@ def main(argv=None):
         gammas = [args.centroid_threshold]
     else:
         gammas = [2.0 ** k for k in range(MIN_POW_2, MAX_POW_2 + 1)]
-    for g in gammas:
+    if len(gammas) == 1 and max(len(s) for _, s in recs) < 512:
+        # one threshold, short records: the host fold (a launch per anti-diagonal would cost more)
+        path = os.path.join(args.output_dir_path, f"centroid_threshold={fmt_f32(gammas[0])}.fa")
+        write_centroid_fold(mats, recs, gammas[0], path)
+        return 0
+    # every threshold of a record in one device sweep (bit-identical to the host fold)
+    ctx = Context(fold_score_sets)
+    folds = [centroid_fold_multi(ctx, m, len(seq), gammas) for (_, seq), m in zip(recs, mats)]
+    ctx.close()
+    for x, g in enumerate(gammas):
         path = os.path.join(args.output_dir_path, f"centroid_threshold={fmt_f32(g)}.fa")
-        write_centroid_fold(mats, recs, g, path)
+        parts = [f">{rna_id}\n" + get_fold_str(folds[rna_id][x], len(seq))
+                 for rna_id, (_, seq) in enumerate(recs)]
+        with open(path, "w") as fh:
+            fh.write("\n".join(parts))
     return 0
 
 

@@ -28,6 +28,23 @@ def centroid_fold(basepair_probs, seq_len, centroid_threshold):
     return CentroidFold([(int(a), int(b)) for a, b in pairs[:npairs.value]], float(acc.value))
 
 
+def centroid_fold_multi(ctx, basepair_probs, seq_len, centroid_thresholds):
+    """The folds of one bpp matrix for several thresholds at once, the Theta(n^3) fill on the GPU
+    of `ctx` (rnamc_centroid_fold_multi; what src/bin/centroid_fold.rs:147-161 loops over).
+    Bit-identical to centroid_fold per threshold.  Returns a list of CentroidFold."""
+    packed = np.ascontiguousarray(basepair_probs.packed, dtype=np.float32)
+    g = np.ascontiguousarray(centroid_thresholds, dtype=np.float32)
+    maxp = max(seq_len // 2, 1)
+    pairs = np.zeros((len(g), maxp, 2), dtype=np.uint32)
+    npairs = np.zeros(len(g), dtype=np.uint32)
+    acc = np.zeros(len(g), dtype=np.float32)
+    _lib.check(_lib.lib().rnamc_centroid_fold_multi(ctx._h, packed.ctypes.data, seq_len, g.ctypes.data,
+                                                    len(g), pairs.ctypes.data, maxp,
+                                                    npairs.ctypes.data, acc.ctypes.data))
+    return [CentroidFold([(int(a), int(b)) for a, b in pairs[x, :npairs[x]]], float(acc[x]))
+            for x in range(len(g))]
+
+
 def get_fold_str(fold, seq_len):
     """src/bin/centroid_fold.rs:197-207"""
     s = [UNPAIR] * seq_len

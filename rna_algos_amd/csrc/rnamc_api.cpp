@@ -1443,6 +1443,82 @@ int rnamc_fold_scores(rnamc_ctx* c, const uint8_t* bases, uint32_t n, int uses_c
   return RNAMC_OK;
 }
 
+int rnamc_centroid_fold_multi(rnamc_ctx* c, const float* bpp_packed, uint32_t n,
+                              const float* centroid_thresholds, uint32_t n_thresholds,
+                              uint32_t* pairs_out, uint32_t max_pairs, uint32_t* n_pairs,
+                              float* expect_accuracy) {
+  if (!c || !bpp_packed || !centroid_thresholds || !n_pairs || n == 0 || n_thresholds == 0)
+    return RNAMC_ERR_INVALID_ARG;
+  if (n > RNAMC_MAX_SEQ_LEN) return RNAMC_ERR_SEQ_TOO_LONG;
+  if (n_thresholds > 65535u) return RNAMC_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  DeviceGuard guard(c->device);
+  if (!guard.ok) return RNAMC_ERR_NO_DEVICE;
+  hipStream_t st = c->own_stream;
+  const uint32_t ld = ((n + 31u) & ~31u) + 32u;
+  const uint64_t msz = ((static_cast<uint64_t>(ld) * n + 63ull) & ~63ull) + 64ull;
+  const uint64_t tri = rnamc_bpp_len(n);
+  // workspace: per threshold two matrices, then the bpp triangle and the thresholds
+  const uint64_t mats = 2ull * msz * n_thresholds;
+  const uint64_t need = mats + ((tri + 63ull) & ~63ull) + ((n_thresholds + 63ull) & ~63ull);
+  HIPCHK(hipStreamSynchronize(st));
+  int rc = ensure_ws(c, need);
+  if (rc) return rc;
+  float* d_m = c->d_ws;
+  float* d_bpp = d_m + mats;
+  float* d_g = d_bpp + ((tri + 63ull) & ~63ull);
+  HIPCHK(hipMemsetAsync(d_m, 0, mats * sizeof(float), st));  // M = 0 below and on the diagonal
+  HIPCHK(hipMemcpyAsync(d_bpp, bpp_packed, tri * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_g, centroid_thresholds, n_thresholds * sizeof(float), hipMemcpyHostToDevice, st));
+  CentroidBatch a{};
+  a.bpp = d_bpp;
+  a.m = d_m;
+  a.gammas = d_g;
+  a.n = n;
+  a.ld = ld;
+  a.msz = msz;
+  for (uint32_t d = 1; d < n; d++) launch_centroid(a, d, n_thresholds, st);
+  HIPCHK(hipGetLastError());
+  // the row-major matrices back to the host; traceback per threshold on host threads
+  std::vector<float> host;
+  try {
+    host.resize(static_cast<size_t>(msz) * n_thresholds);
+  } catch (...) {
+    (void)hipStreamSynchronize(st);
+    return RNAMC_ERR_OOM;
+  }
+  for (uint32_t g = 0; g < n_thresholds; g++)
+    HIPCHK(hipMemcpyAsync(host.data() + static_cast<size_t>(g) * msz, d_m + 2ull * msz * g,
+                          msz * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  auto prob = [&](uint32_t i, uint32_t j) { return bpp_packed[rnamc_bpp_index(n, i, j)]; };
+  std::atomic<uint32_t> next{0};
+  auto work = [&]() {
+    for (;;) {
+      const uint32_t g = next.fetch_add(1);
+      if (g >= n_thresholds) return;
+      const float* m = host.data() + static_cast<size_t>(g) * msz;
+      auto M = [&](size_t r, size_t col) { return m[r * ld + col]; };
+      n_pairs[g] = centroid_traceback(n, centroid_thresholds[g], M, prob,
+                                      pairs_out ? pairs_out + static_cast<size_t>(g) * 2u * max_pairs : nullptr,
+                                      max_pairs);
+      if (expect_accuracy) expect_accuracy[g] = M(0, n - 1);
+    }
+  };
+  const unsigned hw = std::max(1u, std::min<unsigned>({16u, std::thread::hardware_concurrency(), n_thresholds}));
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < hw; t++) {
+    try {
+      pool.emplace_back(work);
+    } catch (...) {
+      break;
+    }
+  }
+  work();
+  for (auto& t : pool) t.join();
+  return RNAMC_OK;
+}
+
 int rnamc_durbin_batch(rnamc_ctx* c, const rnamc_align_scores* scores, uint32_t n_seqs,
                        const uint8_t* bases, const uint64_t* offsets, uint32_t n_pairs,
                        const uint32_t* pair_a, const uint32_t* pair_b, float* match_probs,

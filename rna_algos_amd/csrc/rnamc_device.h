@@ -71,6 +71,17 @@ void launch_durbin(const DurbinPair* d_pairs, uint32_t n_pairs, uint32_t max_cel
 void launch_finalize(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, uint32_t dmin_out,
                      hipStream_t st);
 
+// gamma-centroid fold (rnamc_centroid.hip): per threshold g two dense n x n matrices of msz
+// floats at m + g * 2 * msz (row-major, then column-major), row stride ld, zero-initialised
+struct CentroidBatch {
+  const float* bpp;     // packed diagonal-major triangle, absent pairs negative (device)
+  float* m;
+  const float* gammas;  // device
+  uint32_t n, ld;
+  uint64_t msz;
+};
+void launch_centroid(const CentroidBatch& a, uint32_t d, uint32_t n_gammas, hipStream_t st);
+
 // ---- tree-order summation mode (rnamc_tree.hip) ----
 // Dense n x n matrices with row stride ld (>= n + 32, a multiple of 32 floats), msz floats
 // each; "row" = [i * ld + j], "col" = [j * ld + i].  The outside sweep reuses four slots.

@@ -454,37 +454,8 @@ int rnamc_centroid_fold(const float* bpp_packed, uint32_t n, float centroid_thre
       M(i, j) = best;
     }
   }
-  uint32_t np = 0;
-  std::vector<std::pair<uint32_t, uint32_t>> stack;
-  stack.emplace_back(0u, n - 1);
-  while (!stack.empty()) {
-    auto [i, j] = stack.back();
-    stack.pop_back();
-    if (j <= i) continue;
-    float best = M(i, j);
-    if (best == 0.f) continue;
-    if (best == M(i + 1, j)) {
-      stack.emplace_back(i + 1, j);
-    } else if (best == M(i, j - 1)) {
-      stack.emplace_back(i, j - 1);
-    } else if (prob(i, j) >= -0.5f &&
-               best == M(i + 1, j - 1) + centroid_threshold * prob(i, j) - 1.f) {
-      stack.emplace_back(i + 1, j - 1);
-      if (pairs_out && np < max_pairs) {
-        pairs_out[2 * np] = i;
-        pairs_out[2 * np + 1] = j;
-      }
-      np++;
-    } else {
-      for (uint32_t k = i + 1; k < j; k++) {
-        if (best == M(i, k) + M(k + 1, j)) {
-          stack.emplace_back(i, k);
-          stack.emplace_back(k + 1, j);
-          break;
-        }
-      }
-    }
-  }
+  const uint32_t np = rnamc::centroid_traceback(
+      n, centroid_threshold, [&](size_t r, size_t c) { return acc[r * n + c]; }, prob, pairs_out, max_pairs);
   *n_pairs = np;
   if (expect_accuracy) *expect_accuracy = M(0, n - 1);
   return RNAMC_OK;

@@ -5,6 +5,8 @@
 
 #include <cstdint>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "../../include/rnamc.h"
 
@@ -52,6 +54,46 @@ struct SeqDesc {
   uint64_t c64_off;   // float offset of the u32 table: canonical cells before position 64*w
                       // of diagonal D at [w * (n + 64) + D]
 };
+
+// Traceback of the gamma-centroid fold (src/centroid_fold.rs:64-102): exact float equality
+// tests in the order left-skip, right-skip, pair, first bifurcation k.  M(r, c) reads the filled
+// matrix (0 below and on the main diagonal), prob(i, j) the bpp entry (negative = absent).
+template <class MatFn, class ProbFn>
+inline uint32_t centroid_traceback(uint32_t n, float centroid_threshold, MatFn&& M, ProbFn&& prob,
+                                   uint32_t* pairs_out, uint32_t max_pairs) {
+  uint32_t np = 0;
+  std::vector<std::pair<uint32_t, uint32_t>> stack;
+  stack.emplace_back(0u, n - 1);
+  while (!stack.empty()) {
+    auto [i, j] = stack.back();
+    stack.pop_back();
+    if (j <= i) continue;
+    const float best = M(i, j);
+    if (best == 0.f) continue;
+    if (best == M(i + 1, j)) {
+      stack.emplace_back(i + 1, j);
+    } else if (best == M(i, j - 1)) {
+      stack.emplace_back(i, j - 1);
+    } else if (prob(i, j) >= -0.5f &&
+               best == M(i + 1, j - 1) + centroid_threshold * prob(i, j) - 1.f) {
+      stack.emplace_back(i + 1, j - 1);
+      if (pairs_out && np < max_pairs) {
+        pairs_out[2 * np] = i;
+        pairs_out[2 * np + 1] = j;
+      }
+      np++;
+    } else {
+      for (uint32_t k = i + 1; k < j; k++) {
+        if (best == M(i, k) + M(k + 1, j)) {
+          stack.emplace_back(i, k);
+          stack.emplace_back(k + 1, j);
+          break;
+        }
+      }
+    }
+  }
+  return np;
+}
 
 }  // namespace rnamc
 

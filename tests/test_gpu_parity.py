@@ -769,3 +769,39 @@ def test_librnamc_first_then_torch():
     # one HIP runtime in the process
     mapped = [ln for ln in text.splitlines() if ln.strip().startswith("mapped:")][-1]
     assert mapped.count("libamdhip64") == 1, mapped
+
+
+def test_centroid_fold_multi_gpu(ctx, params, trnas):
+    """rnamc_centroid_fold_multi (the Theta(n^3) (max,+) fill on the GPU for all 18 thresholds of
+    src/bin/centroid_fold.rs:147-161 at once): pairs, push order and expect_accuracy
+    bit-identical to the host fold rnamc_centroid_fold and to the oracle, on the tRNAs' GPU bpp
+    and on synthetic bpp of n = 1024 and 2048 (both kernel shapes: one wave / one workgroup per
+    cell)."""
+    from rna_algos_amd.centroid_fold import centroid_fold, centroid_fold_multi
+    from rna_algos_amd.mccaskill_algo import BppMatrix
+    gammas = [2.0 ** k for k in range(-7, 11)]
+    seqs = [r[1] for r in trnas]
+    for contra in (False, True):
+        mats, _ = ctx.bpp_batch(seqs, contra, False)
+        for s, m in zip(seqs, mats):
+            folds = centroid_fold_multi(ctx, m, len(s), gammas)
+            for g, f in zip(gammas, folds):
+                ref_pairs, ref_acc = O.centroid_fold(m.packed, len(s), g)
+                assert f.basepair_pos_pairs == ref_pairs and np.float32(f.expect_accuracy) == np.float32(ref_acc)
+    rng = np.random.default_rng(3)
+    for n, gs in ((1024, [0.5, 2.0, 6.0, 64.0]), (2048, [1.0, 8.0])):
+        # sparse synthetic bpp: ~3 candidate partners per base, probabilities in (0, 1), near-ties
+        # (multiples of 1/16) so that the traceback's equality tests are exercised
+        packed = np.full(n * (n + 1) // 2, -1.0, dtype=np.float32)
+        for _ in range(3 * n):
+            i = int(rng.integers(0, n - 5))
+            j = int(rng.integers(i + 4, n))
+            d = j - i
+            packed[d * n - d * (d - 1) // 2 + i] = np.float32(rng.integers(1, 16) / 16.0)
+        m = BppMatrix(n, packed)
+        folds = centroid_fold_multi(ctx, m, n, gs)
+        for g, f in zip(gs, folds):
+            h = centroid_fold(m, n, g)
+            assert f.basepair_pos_pairs == h.basepair_pos_pairs, (n, g)
+            assert np.float32(f.expect_accuracy) == np.float32(h.expect_accuracy)
+            assert g < 6.0 or len(f.basepair_pos_pairs) > 0  # (gamma * p - 1 < 0 for small gamma: no pair)
