@@ -235,7 +235,7 @@ int rnamc_ctx_set_params(rnamc_ctx* ctx, const rnamc_params* params);
  *     rnamc_debug_fetch always use mode 0.
  * Tuning (all optional): "group_max_seqs","group_max_nt","group_ws_bytes","block_threads",
  * "fuse_inside","dual_outside","dual_min_cells","dual_max_diag","order_inside","order_outside",
- * "latency_mode","lat_max_cells","lat_inside","lat_inside_waves","lat_e_waves","lat_pairs",
+ * "latency_mode","lat_max_cells","lat_inside","lat_e_waves","lat_pairs",
  * "lat_merge","lat_zr_ahead","profile"; tree-order mode: "tree_two" (two anti-diagonals per
  * launch, default 1), "tree_tpc" (threads per cell: 64 / 256 / 1024, 0 = by diagonal size). */
 int rnamc_ctx_set(rnamc_ctx* ctx, const char* name, int64_t value);

@@ -92,14 +92,11 @@ struct rnamc_ctx {
   // that under CONTRAfold), 2 always
   int64_t latency_mode = 1;
   int64_t lat_max_cells = 32768;
-  // inside folds of such a group (lat_inside is a bit set, 0 = the three-lanes-per-cell form
-  // throughout): bit 0 one wave per chain (terms classified ahead of the chain, as in the
-  // outside forms) on the diagonals whose launches hold at most lat_inside_waves chains (3 per
-  // cell); bit 1 eight chains per wave with the 8-lane speculative logsumexp on the diagonals
-  // whose launches need at most lat_e_waves waves (beyond ~2 waves per SIMD that form is
-  // issue-bound and loses: profiles/r02_latency_forms.txt)
+  // inside folds of such a group: lat_inside != 0 takes the eight-chains-per-wave form (8-lane
+  // speculative logsumexp) on the diagonals whose launches need at most lat_e_waves waves (beyond
+  // ~2 waves per SIMD that form is issue-bound and loses: profiles/r02_latency_forms.txt), the
+  // three-lanes-per-cell form elsewhere
   int64_t lat_inside = 2;
-  int64_t lat_inside_waves = 2048;
   int64_t lat_e_waves = 2048;
   // debug: probs_multibranch and the pair-probability chains as two launches (timing splits)
   int64_t lat_split = 0;
@@ -383,9 +380,7 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
         need_pairs(d);  // (only the first diagonal finds work here)
         const bool pair_next = heads_done < static_cast<int64_t>(d) + 1 && d + 1 < gmax;
         const uint32_t pv = (d + ring - 1) % ring, cu = d % ring;
-        // One wave per chain while the launch's 3 x cells chains leave every chain wave
-        // (nearly) a SIMD of its own, the three-lanes-per-cell form before that.  The
-        // wave forms complete sums_1ormore_basepairs of diagonal d-1 in the launch
+        // The eight-chains form completes sums_1ormore_basepairs of diagonal d-1 in the launch
         // of diagonal d (sequences that end at d-1 included).
         const uint64_t chains = 3ull * (gmax - d) * active(d);
         // (CONTRAfold, eight-chains form: two more chain kinds per cell, see lat_zr_ahead)
@@ -393,11 +388,8 @@ int run_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const uint6
         // (CONTRAfold: three times the waves — its three-lanes form folds two chains per cell
         // one after the other, measured crossover in profiles/r02_latency_forms.txt)
         const uint64_t e_waves = static_cast<uint64_t>(c->lat_e_waves) * (contra ? 3 : 1);
-        // lat_inside bit 0: one wave per chain on the diagonals with few chains; bit 1: eight
-        // chains per wave on the diagonals with few enough waves
-        const int form = !do_sums ? 0
-                         : ((c->lat_inside & 1) && chains <= static_cast<uint64_t>(c->lat_inside_waves)) ? 1
-                         : ((c->lat_inside & 2) && (chains / 3 * kinds_e + 7) / 8 <= e_waves) ? 2 : 0;
+        // eight chains per wave on the diagonals with few enough waves
+        const int form = (do_sums && c->lat_inside != 0 && (chains / 3 * kinds_e + 7) / 8 <= e_waves) ? 2 : 0;
         const bool wave_form = form != 0;
         // CONTRAfold: a cell's sums_rightmost_basepairs folds (d steps) precede its other
         // folds (d steps more); all but their last step needs nothing of diagonal d, so the
@@ -1102,10 +1094,8 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     c->latency_mode = value;
   } else if (k == "lat_max_cells" && value >= 0) {
     c->lat_max_cells = value;
-  } else if (k == "lat_inside" && value >= 0 && value <= 3) {
+  } else if (k == "lat_inside" && (value == 0 || value == 2)) {
     c->lat_inside = value;
-  } else if (k == "lat_inside_waves" && value >= 0) {
-    c->lat_inside_waves = value;
   } else if (k == "lat_split") {
     c->lat_split = value;
   } else if (k == "lat_merge") {
@@ -1565,6 +1555,7 @@ int rnamc_durbin_batch(rnamc_ctx* c, const rnamc_align_scores* scores, uint32_t 
   // pairs in chunks whose six matrices per pair fit the workspace budget
   const uint64_t ws_cap = static_cast<uint64_t>(std::max<int64_t>(c->group_ws_bytes, 1)) / 4;
   std::vector<DurbinPair> chunk;
+  std::vector<float> h_out;
   for (uint32_t p0 = 0; p0 < n_pairs;) {
     chunk.clear();
     uint64_t ws = 0, out = 0;
@@ -1605,11 +1596,19 @@ int rnamc_durbin_batch(rnamc_ctx* c, const rnamc_align_scores* scores, uint32_t 
     launch_durbin(d_pairs, static_cast<uint32_t>(chunk.size()), max_cells, d_bases, c->d_ws, d_out,
                   *scores, st);
     HIPCHK_D(hipGetLastError());
-    for (size_t x = 0; x < chunk.size(); x++)
-      HIPCHK_D(hipMemcpyAsync(match_probs + out_offsets[p0 + x], d_out + chunk[x].out_off,
-                              static_cast<uint64_t>(chunk[x].n1) * chunk[x].n2 * sizeof(float),
-                              hipMemcpyDeviceToHost, st));
+    // one D2H per chunk, scattered on the host (a FASTA of many short records makes tens of
+    // thousands of pairs: one copy each would cost more than the sweeps)
+    try {
+      h_out.resize(out);
+    } catch (...) {
+      cleanup();
+      return RNAMC_ERR_OOM;
+    }
+    HIPCHK_D(hipMemcpyAsync(h_out.data(), d_out, out * sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK_D(hipStreamSynchronize(st));
+    for (size_t x = 0; x < chunk.size(); x++)
+      std::memcpy(match_probs + out_offsets[p0 + x], h_out.data() + chunk[x].out_off,
+                  static_cast<uint64_t>(chunk[x].n1) * chunk[x].n2 * sizeof(float));
     p0 = p;
   }
 #undef HIPCHK_D

@@ -1388,12 +1388,12 @@ __global__ void __launch_bounds__(64) k_inside_lat(DeviceBatch b, uint32_t d, ui
     return;
   }
   bx -= pair_cells;
-  // form 1: one wave per (cell, role); form 2: eight cells of one role per wave; 0: no chains;
-  // form 2 | 4 (CONTRAfold): roles 3, 4 as well (the sums_rightmost_basepairs folds of diagonal
-  // d + 1 up to their last step); | 8: this diagonal's were parked by the launch before
+  // form 2: eight cells of one role per wave; 0: no chains; form 2 | 4 (CONTRAfold): roles 3, 4
+  // as well (the sums_rightmost_basepairs folds of diagonal d + 1 up to their last step); | 8:
+  // this diagonal's were parked by the launch before
   const bool ahead = CONTRA && (form & 7) == 6, parked = CONTRA && (form & 11) == 10;
   form &= 3;
-  const uint32_t per = form == 2 ? 8u : 1u;
+  const uint32_t per = 8u;
   const uint32_t kinds = ahead ? 5u : 3u;
   const uint32_t wpr = (cells_max + per - 1u) / per;  // waves per role
   const uint32_t nchain = form ? kinds * wpr : 0u;
@@ -1401,15 +1401,11 @@ __global__ void __launch_bounds__(64) k_inside_lat(DeviceBatch b, uint32_t d, ui
     const uint32_t w = bx / kinds, role = bx - kinds * w;
     if (d >= n || w * per >= n - d) return;
     const Piece8 P8 = load_piece8();
-    if (form == 2) {
-      if (role == 0) inside_chain_e<CONTRA, 0>(b, q, d, w * 8u, P8, parked);
-      else if (role == 1) inside_chain_e<CONTRA, 1>(b, q, d, w * 8u, P8, parked);
-      else if (role == 2) inside_chain_e<CONTRA, 2>(b, q, d, w * 8u, P8, parked);
-      else if (CONTRA && role == 3) inside_chain_e<CONTRA, 3>(b, q, d, w * 8u, P8, false);
-      else if (CONTRA) inside_chain_e<CONTRA, 4>(b, q, d, w * 8u, P8, false);
-    } else {
-      inside_chain_lat<CONTRA>(b, q, d, w, role, P8);
-    }
+    if (role == 0) inside_chain_e<CONTRA, 0>(b, q, d, w * 8u, P8, parked);
+    else if (role == 1) inside_chain_e<CONTRA, 1>(b, q, d, w * 8u, P8, parked);
+    else if (role == 2) inside_chain_e<CONTRA, 2>(b, q, d, w * 8u, P8, parked);
+    else if (CONTRA && role == 3) inside_chain_e<CONTRA, 3>(b, q, d, w * 8u, P8, false);
+    else if (CONTRA) inside_chain_e<CONTRA, 4>(b, q, d, w * 8u, P8, false);
   } else {
     if (!do_combine || d == 0 || d - 1 >= n) return;
     const uint32_t i0 = (bx - nchain) * 64u;
@@ -1769,7 +1765,7 @@ void launch_inside_lat(const DeviceBatch& b, bool contra, uint32_t d, uint32_t m
                        int form, bool do_combine, uint32_t pair_d, hipStream_t st) {
   if (nseq == 0) return;
   const uint32_t cells = ((form & 3) && d < max_n) ? max_n - d : 0;
-  const uint32_t per = (form & 3) == 2 ? 8u : 1u;
+  const uint32_t per = 8u;
   const uint32_t waves = ((form & 4) ? 5u : 3u) * ((cells + per - 1u) / per);
   const uint32_t cb = (do_combine && d >= 1 && d - 1 < max_n) ? (max_n - d + 1 + 63) / 64 : 0;
   const uint32_t pc = (pair_d != 0 && pair_d < max_n) ? max_n - pair_d : 0;  // pair_d 0: none

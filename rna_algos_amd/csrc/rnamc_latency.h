@@ -162,6 +162,9 @@ __device__ __forceinline__ float far_steps(float s, float t) {
 template <int NT>
 __device__ __forceinline__ float fold_block(float sum, const float (&a)[NT], float* buf,
                                             const Piece8& P8) {
+  // far_limit's margins are derived for blocks of at most 256 steps (tests/test_oracle_cpu.py
+  // checks the per-piece bound r(z) >= z - eps they rest on)
+  static_assert(NT * 64 <= 256, "fold_block: the sure-far margins cover at most 256 steps per block");
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t pos = 0, total = 0;
   float mag = 0.f;
@@ -223,100 +226,12 @@ __device__ __forceinline__ float fold_block(float sum, const float (&a)[NT], flo
 
 
 // ----------------------------------------------------------------------------
-// inside: one wave per (cell, role) of diagonal d
+// inside, eight chains per wave: lanes 8g..8g+7 hold the chain of cell cell0 + g, one role per wave
 //   role 0: sums_rightmost_basepairs_external (CONTRAfold: its own fold) and sums_external
 //   role 1: (CONTRAfold: sums_rightmost_basepairs_multibranch and) the first sum of 364-374 /
-//           499-512, parked in the sums_1ormore slot until the combine below
+//           499-512, parked in the sums_1ormore slot until inside_combine_lat
 //   role 2: sums_multibranch
-// Same operations per chain as inside_sums_cell.
-template <bool CONTRA>
-__device__ __forceinline__ void inside_chain_lat(const DeviceBatch& b, const Seq& q, uint32_t d,
-                                                 uint32_t i, uint32_t role, const Piece8& P8) {
-  const uint32_t n = q.n;
-  const uint32_t od = tri_off(n, d) + i;
-  const uint32_t lane = threadIdx.x & 63u;
-  const float* __restrict__ zre = q.m[M_ZRE];
-  const float* __restrict__ zrm = q.m[CONTRA ? M_ZRM : M_ZRE];
-  const float* __restrict__ qa = q.m[M_QA];
-  const bool lane0 = lane == 0u;
-  __shared__ float steps[64];
-  float zr = kNegInf, c = 0.f, mun = 0.f;
-  if (!CONTRA) {
-    // sums_rightmost_basepairs_external(i,j) = that of (i,j-1) extended by one step (344-351)
-    const float prev = (d >= 1) ? zre[tri_off(n, d - 1) + i] : kNegInf;
-    zr = lse_u(prev, qa[od], P8);
-    if (lane0 && role == 0) q.m[M_ZRE][od] = zr;
-    c = b.params->turner.coeff_num_branches;
-  } else {
-    const rnamc_fold_score_sets& f = b.params->contra;
-    mun = f.multibranch_score_unpair;
-    if (role < 2 && d >= 1) {
-      // (468-486): steps t = 1..d, k = i + t: x + P + Q * (j - k) with
-      // (P, Q) = (ext_bp, ext_unpair) / (mb_bp, mb_unpair); lane l loads step t0 + l
-      const float Pc = (role == 0) ? f.external_score_basepair : f.multibranch_score_basepair;
-      const float Qc = (role == 0) ? f.external_score_unpair : mun;
-      struct ABuf {
-        float x;
-      };
-      (void)pingpong<ABuf, 64, true>(
-          1u, (d + 63u) / 64u,
-          [&](ABuf& B, uint32_t t0) { B.x = qa[tri_off(n, min(t0 + lane, d)) + i]; },
-          [&](const ABuf& B, uint32_t t0) {
-            const uint32_t cnt = min(64u, d + 1u - t0);
-            const float bx = pin(B.x);
-            const float a[1] = {lane < cnt ? bx + Pc + Qc * static_cast<float>(d - t0 - lane) : kNegInf};
-            zr = fold_block<1>(zr, a, steps, P8);
-          });
-      if (lane0) q.m[role == 0 ? M_ZRE : M_ZRM][od] = zr;
-    }
-  }
-  // the walk k = i + t:  Zr[k][j] -> diagonal d-t, offset i+t;  Z/Q1[i][k-1] -> diagonal t-1, offset i
-  float acc;
-  if (role == 0) {
-    acc = CONTRA ? lse_u(b.params->contra.external_score_unpair * static_cast<float>(d + 1), zr + 0.f, P8)
-                 : lse_u(0.f, zr + 0.f, P8);  // k = i: Z[i][i-1] is the lower-triangle 0
-  } else if (role == 1) {
-    acc = CONTRA ? zr : zr + c;
-  } else {
-    acc = kNegInf;
-  }
-  const float* __restrict__ pa = (CONTRA && role != 0) ? zrm : zre;
-  const float* __restrict__ pb = q.m[role == 0 ? M_Z : M_Q1D];
-  if (d >= 2) {
-    // steps t = 1 .. d-1; lane l loads the two operands of step t0 + l
-    struct SBuf {
-      float ra, rb;
-    };
-    (void)pingpong<SBuf, 64, true>(
-        1u, (d - 1u + 63u) / 64u,
-        [&](SBuf& B, uint32_t t0) {
-          const uint32_t t = min(t0 + lane, d - 1u);
-          B.ra = pa[tri_off(n, d - t) + t + i];
-          B.rb = pb[tri_off(n, t - 1u) + i];
-        },
-        [&](const SBuf& B, uint32_t t0) {
-          const uint32_t cnt = min(64u, d - t0);
-          const float ra = pin(B.ra), rb = pin(B.rb);
-          float a;  // the term of step t0 + lane
-          if (!CONTRA) {
-            a = (role == 0) ? ra + rb : (role == 1 ? ra + c : rb + (ra + c));
-          } else {
-            a = (role == 1) ? ra + mun * static_cast<float>(t0 + lane) : rb + ra;
-          }
-          const float t[1] = {lane < cnt ? a : kNegInf};
-          acc = fold_block<1>(acc, t, steps, P8);
-        });
-  }
-  if (lane0) {
-    if (role == 0) q.m[M_Z][od] = acc;
-    if (role == 1) q.m[M_Q1D][od] = acc;  // parked: inside_combine_lat turns it into sums_1ormore
-    if (role == 2) q.m[M_QM][od] = acc;
-  }
-}
-
-// ----------------------------------------------------------------------------
-// inside, eight chains per wave: lanes 8g..8g+7 hold the chain of cell cell0 + g (one role per
-// wave, as above), lane p of a group evaluates cubic piece p and an OR over the group (3 DPP
+// (same operations per chain as inside_sums_cell); lane p of a group evaluates cubic piece p and an OR over the group (3 DPP
 // steps) picks the piece whose interval holds z: the LDS-table round trips (60 % of a
 // dependent step of the three-lanes-per-cell form) leave the chain.  No scalar fast path here:
 // eight independent chains are hardly ever all in the identity piece at once.

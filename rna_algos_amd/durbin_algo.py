@@ -67,36 +67,44 @@ def with_pseudo_bases(seq):
     return np.concatenate([[PSEUDO_BASE], seq, [PSEUDO_BASE]]).astype(np.uint8)
 
 
+# one device context per process for calls without an explicit one (the reference's callers run
+# one durbin_algo per pair from a pool: a context per call would spend its time on streams,
+# events and workspace allocation)
+_ctx = None
+
+
+def _default_context():
+    global _ctx
+    if _ctx is None:
+        from .mccaskill_algo import Context
+        from .utils import FoldScoreSets
+        # the pair-HMM reads none of the folding tables: any parameter block will do
+        _ctx = Context(FoldScoreSets.new(0.0))
+    return _ctx
+
+
 def durbin_algo_batch(seqs, pairs, align_scores, ctx=None):
     """seqs: sequences WITH pseudo bases; pairs: list of (a, b) indices.  -> list of ProbMat
     (np.float32 arrays of shape (len(a), len(b))), what src/bin/durbin_algo.rs:55-75 computes
     with one pool task per pair."""
-    from .mccaskill_algo import Context
-    from .utils import FoldScoreSets
-    own = ctx is None
-    if own:
-        # the pair-HMM reads none of the folding tables: any parameter block will do
-        ctx = Context(FoldScoreSets.new(0.0))
-    try:
-        seqs = [np.ascontiguousarray(s, dtype=np.uint8) for s in seqs]
-        lens = np.array([len(s) for s in seqs], dtype=np.uint64)
-        offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
-        np.cumsum(lens, out=offsets[1:])
-        bases = np.concatenate(seqs) if seqs else np.zeros(0, np.uint8)
-        pa = np.array([p[0] for p in pairs], dtype=np.uint32)
-        pb = np.array([p[1] for p in pairs], dtype=np.uint32)
-        sizes = np.array([int(lens[a]) * int(lens[b]) for a, b in pairs], dtype=np.uint64)
-        out_offsets = np.zeros(len(pairs) + 1, dtype=np.uint64)
-        np.cumsum(sizes, out=out_offsets[1:])
-        out = np.empty(int(out_offsets[-1]), dtype=np.float32)
-        _lib.check(_lib.lib().rnamc_durbin_batch(
-            ctx._h, align_scores.ptr, len(seqs), bases.ctypes.data, offsets.ctypes.data, len(pairs),
-            pa.ctypes.data, pb.ctypes.data, out.ctypes.data, out_offsets.ctypes.data))
-        return [out[int(out_offsets[p]):int(out_offsets[p + 1])].reshape(int(lens[a]), int(lens[b]))
-                for p, (a, b) in enumerate(pairs)]
-    finally:
-        if own:
-            ctx.close()
+    if ctx is None:
+        ctx = _default_context()
+    seqs = [np.ascontiguousarray(s, dtype=np.uint8) for s in seqs]
+    lens = np.array([len(s) for s in seqs], dtype=np.uint64)
+    offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=offsets[1:])
+    bases = np.concatenate(seqs) if seqs else np.zeros(0, np.uint8)
+    pa = np.array([p[0] for p in pairs], dtype=np.uint32)
+    pb = np.array([p[1] for p in pairs], dtype=np.uint32)
+    sizes = np.array([int(lens[a]) * int(lens[b]) for a, b in pairs], dtype=np.uint64)
+    out_offsets = np.zeros(len(pairs) + 1, dtype=np.uint64)
+    np.cumsum(sizes, out=out_offsets[1:])
+    out = np.empty(int(out_offsets[-1]), dtype=np.float32)
+    _lib.check(_lib.lib().rnamc_durbin_batch(
+        ctx._h, align_scores.ptr, len(seqs), bases.ctypes.data, offsets.ctypes.data, len(pairs),
+        pa.ctypes.data, pb.ctypes.data, out.ctypes.data, out_offsets.ctypes.data))
+    return [out[int(out_offsets[p]):int(out_offsets[p + 1])].reshape(int(lens[a]), int(lens[b]))
+            for p, (a, b) in enumerate(pairs)]
 
 
 def durbin_algo(seq_pair, align_scores, ctx=None):

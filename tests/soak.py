@@ -44,9 +44,8 @@ def main():
             "lat_pairs": int(rng.integers(0, 2)),
             "lat_merge": int(rng.integers(0, 2)),
             "lat_zr_ahead": int(rng.integers(0, 2)),
-            "lat_inside": int(rng.integers(0, 4)),
+            "lat_inside": int(rng.choice([0, 2])),
             "lat_e_waves": int(rng.choice([0, 64, 2048, 1 << 20])),
-            "lat_inside_waves": int(rng.choice([0, 300, 2048, 1 << 20])),
         }
         for k, v in knobs.items():
             ctx.set(k, v)

@@ -612,11 +612,9 @@ def test_latency_forms_bit_exact(params, contra, short):
         ctx.set("latency_mode", 2)
         lat, logz1 = ctx.bpp_batch(seqs, contra, short)
         ctx.set("group_max_seqs", 5)  # several small groups
-        ctx.set("lat_inside", 1)      # ... whose inside folds run one wave per chain as well
-        ctx.set("lat_inside_waves", 1 << 20)
+        ctx.set("lat_inside", 0)      # ... whose inside folds stay in the three-lanes-per-cell form
         lat2, logz2 = ctx.bpp_batch(seqs, contra, short)
-        ctx.set("lat_inside_waves", 300)  # (mixed: three-lanes form first, wave form at the end)
-        ctx.set("lat_pairs", 0)           # (2-loop blocks in their lane-per-cell form)
+        ctx.set("lat_pairs", 0)       # (2-loop blocks in their lane-per-cell form)
         lat3, logz4 = ctx.bpp_batch(seqs, contra, short)
         ctx.set("lat_inside", 2)          # eight chains per wave, 8-lane speculative logsumexp
         ctx.set("lat_pairs", 1)
@@ -625,11 +623,9 @@ def test_latency_forms_bit_exact(params, contra, short):
         lat4, logz5 = ctx.bpp_batch(seqs, contra, short)
         ctx.set("lat_merge", 1)
         ctx.set("lat_zr_ahead", 1)
-        ctx.set("lat_inside", 3)          # both: wave per chain below 300 chains, else eight per wave
-        ctx.set("lat_e_waves", 200)       # (and the three-lanes form above 200 waves)
+        ctx.set("lat_e_waves", 200)       # (the three-lanes form above 200 waves, eight chains below)
         lat5, logz6 = ctx.bpp_batch(seqs, contra, short)
         ctx.set("lat_e_waves", 2048)
-        ctx.set("lat_inside_waves", 2048)
         ctx.set("latency_mode", 1)    # default: a lone sequence takes the latency forms
         one, logz3 = ctx.bpp_batch([seqs[-4]], contra, short)
     finally:

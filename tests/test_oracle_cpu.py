@@ -258,3 +258,35 @@ def test_exact_evaluation_against_bruteforce(params):
                         assert v < 0 or v <= 1e-30
                     assert (rb[o] >= -0.5) == (v >= -0.5)  # same key set as the reference restatement
                     o += 1
+
+
+def test_logsumexp_pieces_never_lower_the_sum_by_more_than_rounding():
+    """What the sure-far classification of the latency forms rests on (rnamc_latency.h,
+    far_limit): a fold step returns  lo + r(z)  with  r(z) >= z - eps  for every cubic piece of
+    ln_exp_1p (src/utils.rs:602-627), i.e. never less than the larger operand minus a rounding-
+    sized eps, so that over a block of at most 256 steps the running sum cannot drop by the margin
+    (1 while |values| < 2^12).  Swept over every piece in f32, operation for operation."""
+    F = np.float32
+    brk = [0.0, 0.66153675, 1.6320158, 2.4912589, 3.3792500, 4.426169, 5.789071, 7.8162727, 11.862479]
+    coef = [(-0.0065591595, 0.12764427, 0.49965546, 0.6931542),
+            (-0.015515756, 0.14467756, 0.48829398, 0.6958093),
+            (-0.012890925, 0.13010283, 0.51503986, 0.6795586),
+            (-0.0072142647, 0.087754086, 0.6208708, 0.5909676),
+            (-0.0031455354, 0.046722945, 0.7592532, 0.43487945),
+            (-0.0010110698, 0.018594341, 0.88317305, 0.25236955),
+            (-0.000196278, 0.0046084408, 0.9634432, 0.09831489),
+            (-0.0000113994, 0.0003734731, 0.9959107, 0.0149855051)]
+    worst = 0.0
+    for p, (a, b, c, d) in enumerate(coef):
+        z = np.linspace(brk[p], brk[p + 1], 200001, dtype=np.float64).astype(F)
+        z = z[(z >= F(brk[p])) & (z < F(brk[p + 1]))]
+        r = ((F(a) * z + F(b)) * z + F(c)) * z + F(d)  # f32, no fusion: numpy rounds every op
+        assert r.dtype == np.float32
+        worst = max(worst, float(np.max(z.astype(np.float64) - r.astype(np.float64))))
+        # and against the exact ln(1 + e^z): the reference's approximation error
+        exact = np.log1p(np.exp(z.astype(np.float64)))
+        assert np.max(np.abs(r.astype(np.float64) - exact)) < 2e-5
+    # r(z) - z >= ln(1 + e^-z) - approximation error > 0 up to the last piece's end, where
+    # ln(1 + e^-11.86) = 7e-6: the pieces may undershoot z by at most their own error
+    assert worst * 256 < 1.0, worst
+    print(f"max (z - r(z)) over all pieces: {worst:.3e}  (x 256 steps = {worst * 256:.3e} < margin 1)")
