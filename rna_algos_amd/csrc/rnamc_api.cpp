@@ -1063,6 +1063,10 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
   const std::string k(name);
   if (k == "summation_mode" && (value == 0 || value == 1)) {
     c->summation_mode = value;
+  } else if (k == "tree_waves" && value >= 64) {
+    tree_policy(value, 0);
+  } else if (k == "tree_short" && value >= 1) {
+    tree_policy(0, value);
   } else if (k == "tree_two") {
     c->tree_two = value;
   } else if (k == "tree_tpc" && (value == 0 || value == 64 || value == 128 || value == 256 || value == 1024)) {

@@ -143,6 +143,8 @@ void launch_tree_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t ma
                         int64_t tpc_knob, bool two, hipStream_t st);
 void launch_tree_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
                          int64_t tpc_knob, bool two, hipStream_t st);
+// threads-per-cell policy: waves a launch may hold, sums up to which one wave per cell is taken
+void tree_policy(int64_t waves, int64_t short_terms);
 // per-cell statics (hairpin / multibranch-close / accessible scores, 2-loop sides), once per group
 void launch_tree_static(const TreeBatch& b, bool contra, uint32_t nseq, uint32_t max_n, hipStream_t st);
 void launch_tree_finalize(const TreeBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st);

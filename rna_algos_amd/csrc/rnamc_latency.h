@@ -590,15 +590,13 @@ __device__ __forceinline__ void inside_pair_lat(const DeviceBatch& b, const Seq&
     // (a scorer call costs ~1.8 us of dependent table lookups however many lanes take part:
     // 8 batches instead of 31 rows)
     const uint32_t nprobe = (lim + 1u) * (lim + 2u) / 2u;
-    // Turner: the bases around i (rightwards) and j (leftwards), for turner_twoloop_flat
+    // the bases around i (rightwards) and j (leftwards), for the flat scorers
     __shared__ Win2 win;
-    if (!CONTRA) {
-      if (lane < 40u) {
-        win.left[lane] = s[min(i + lane, n - 1u)];
-        win.right[lane] = s[j >= lane ? j - lane : 0u];
-      }
-      __builtin_amdgcn_wave_barrier();
+    if (lane < 40u) {
+      win.left[lane] = s[min(i + lane, n - 1u)];
+      win.right[lane] = s[j >= lane ? j - lane : 0u];
     }
+    __builtin_amdgcn_wave_barrier();
     // (a, r) of this lane's probe, carried from batch to batch: row a holds len = lim + 1 - a
     uint32_t pa = 0, plen = lim + 1u, pr = lane;
     auto batch_term = [&](uint32_t m0) {
@@ -619,7 +617,10 @@ __device__ __forceinline__ void inside_pair_lat(const DeviceBatch& b, const Seq&
                                    win.left[2], win.right[1], win.right[2], win.left[1u + a],
                                    win.right[1u + r], win.right[r], win.left[a]);
         } else {
-          sc = model.twoloop(s, i, j, k, l);
+          // (same expression tree as Contra::twoloop, every table lookup issued at once)
+          sc = contra_twoloop_flat(b.params->contra, a, r, win.left[0], win.right[0], win.left[1],
+                                   win.right[1], win.left[1u + a], win.right[1u + r], win.right[r],
+                                   win.left[a]);
         }
         if (x > kNegInf) term = x + sc;
       }
@@ -659,7 +660,6 @@ __device__ __forceinline__ void outside_head_lat(const DeviceBatch& b, const Seq
   const float* __restrict__ lp = q.m[M_P];
   const float qb_ij = qb[od];
   if (uni(__float_as_uint(qb_ij)) == 0xFF800000u) return;  // not in sums_close
-  const auto model = ModelOf<CONTRA>::make(b);
   const float qa_ij = q.m[M_QA][od];
   const float* z = q.m[M_Z];
   const float ztot = z[tri_off(n, n - 1)];
@@ -719,13 +719,25 @@ __device__ __forceinline__ void outside_head_lat(const DeviceBatch& b, const Seq
         cur = nxt;
       }
     } else {
+      // (the bases around i (leftwards) and j (rightwards) for contra_twoloop_flat: same
+      // expression tree as Contra::twoloop, every table lookup issued at once)
+      __shared__ Win2 winc;
+      if (lane < 40u) {
+        winc.left[lane] = s[i >= lane ? i - lane : 0u];
+        winc.right[lane] = s[min(j + lane, n - 1u)];
+      }
+      __builtin_amdgcn_wave_barrier();
       auto row_term = [&](uint32_t a) {
         float term = kNegInf;
         if (a <= lim && a < i && lane <= lim - a && j + 1u + lane <= n - 1u) {
           const uint32_t k = i - 1u - a, l = j + 1u + lane;
           const uint32_t x = tri_off(n, l - k) + k;
           const float qkl = qb[x];
-          if (qkl > kNegInf) term = lp[x] + qb_ij - qkl + model.twoloop(s, k, l, i, j);
+          // (k,l) closes, (i,j) is enclosed
+          const float sc = contra_twoloop_flat(b.params->contra, a, lane, winc.left[1u + a], winc.right[1u + lane],
+                                               winc.left[a], winc.right[lane], winc.left[0], winc.right[0],
+                                               winc.right[1], winc.left[1]);
+          if (qkl > kNegInf) term = lp[x] + qb_ij - qkl + sc;
         }
         return term;
       };

@@ -153,27 +153,31 @@ __device__ __forceinline__ Acc wave_reduce(const Acc& a) {
 // after the barrier the first wave reduces the W = TPC / 64 pairs once more; the other waves
 // are done (returns false for them).
 template <int NA, int TPC>
-__device__ __forceinline__ bool cell_reduce(Acc (&a)[NA], float (*lds)[NA][2]) {
+__device__ __forceinline__ bool cell_reduce(Acc (&a)[NA], float (*lds)[NA][2], int live = NA) {
+  // (`live`, wave-uniform: accumulators [live, NA) are empty in every lane of the group)
 #pragma unroll
-  for (int x = 0; x < NA; x++) a[x] = wave_reduce(a[x]);
+  for (int x = 0; x < NA; x++)
+    if (x < live) a[x] = wave_reduce(a[x]);
   if (TPC == 64) return true;
   constexpr int W = TPC / 64;  // waves per cell group (a 256-thread block holds 256 / TPC groups)
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const uint32_t gw = wave % static_cast<uint32_t>(W), first = wave - gw;
   if (lane == 0u) {
 #pragma unroll
-    for (int x = 0; x < NA; x++) {
-      lds[wave][x][0] = a[x].m;
-      lds[wave][x][1] = a[x].s;
-    }
+    for (int x = 0; x < NA; x++)
+      if (x < live) {
+        lds[wave][x][0] = a[x].m;
+        lds[wave][x][1] = a[x].s;
+      }
   }
   __syncthreads();
   if (gw != 0u) return false;
 #pragma unroll
-  for (int x = 0; x < NA; x++) {
-    Acc t = lane < static_cast<uint32_t>(W) ? Acc{lds[first + lane][x][0], lds[first + lane][x][1]} : acc_empty();
-    a[x] = wave_reduce(t);
-  }
+  for (int x = 0; x < NA; x++)
+    if (x < live) {
+      Acc t = lane < static_cast<uint32_t>(W) ? Acc{lds[first + lane][x][0], lds[first + lane][x][1]} : acc_empty();
+      a[x] = wave_reduce(t);
+    }
   return true;
 }
 
@@ -676,7 +680,8 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
       acc_product<TPC>(acc[8], q.m[T_QA] + row_i + ld + i + 2, q.zs + i + 3, d - 1, t);
   }
   if (t == 0u) acc_add(acc[3], q1_ii);
-  if (!cell_reduce<NA, TPC>(acc, red)) return;
+  // (the sums_external accumulators [5..8] live only in row 0 and in the column n-1 groups)
+  if (!cell_reduce<NA, TPC>(acc, red, (i == 0 || zs0 || zs1) ? NA : 5)) return;
 #ifdef RNAMC_DEBUG_KNOBS
   if (b.debug & 16) {  // timing: no epilogue
     if (t == 0u && acc[0].s + acc[1].s + acc[2].s + acc[3].s + acc[4].s == 12345.f) q.zp[0] = 1.f;
@@ -1018,10 +1023,16 @@ void launch_tree_init(const TreeBatch& b, uint32_t nseq, uint32_t max_n, bool co
 // SIMD, 5120 per chip): a launch whose waves need a second round pays every fixed stage of its
 // dependent chain twice (measured: 8192 waves of 256-thread groups took as long as 4096 would
 // have taken twice).
+static uint64_t g_tree_waves = 5120;  // (rnamc_ctx_set "tree_waves" / "tree_short": tuning)
+static uint32_t g_tree_short = 256;
+void tree_policy(int64_t waves, int64_t short_terms) {
+  if (waves > 0) g_tree_waves = static_cast<uint64_t>(waves);
+  if (short_terms > 0) g_tree_short = static_cast<uint32_t>(short_terms);
+}
 static int tree_tpc(uint64_t cells, uint32_t terms, int64_t knob) {
   if (knob == 64 || knob == 128 || knob == 256 || knob == 1024) return static_cast<int>(knob);
-  constexpr uint64_t kWaves = 4800;
-  if (terms <= 512u || cells * 2u > kWaves) return 64;
+  const uint64_t kWaves = g_tree_waves;
+  if (terms <= g_tree_short || cells * 2u > kWaves) return 64;
   if (cells * 4u > kWaves) return 128;
   if (terms <= 2048u || cells * 16u > kWaves) return 256;
   return 1024;
