@@ -73,6 +73,10 @@ struct rnamc_ctx {
   int64_t summation_mode = 0;
   int64_t tree_tpc = 0;  // tree mode: threads per cell (64 / 256 / 1024), 0 = by diagonal size
   int64_t tree_two = 1;  // tree mode: two diagonals per launch
+  // tree mode: width of a band of diagonals whose products take their mid-field from k_tree_mid
+  // (a multiple of 32, at most 128; 0: every launch walks its sums whole)
+  int64_t tree_band = 32;
+  hipStream_t bulk_stream = nullptr;  // k_tree_mid, beside the sweep (lowest priority)
   int64_t tree_debug = 0;  // (RNAMC_DEBUG_KNOBS builds: bit 0 no 2-loops, 1 no products, 2 empty kernels)
   int64_t group_max_seqs = 8192;
   int64_t group_max_nt = 2ll << 20;  // a group holds ~2M nucleotides (or 64 GB of DP state)
@@ -711,6 +715,19 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
     return (offsets[a + 1] - offsets[a]) > (offsets[b + 1] - offsets[b]);
   });
   const uint64_t ws_cap_floats = static_cast<uint64_t>(std::max<int64_t>(c->group_ws_bytes, 1)) / 4;
+  // banding needs two diagonals per launch aligned to even diagonals, 32-bit operand offsets
+  // inside a sequence's matrices, and sequences long enough to have a banded diagonal at all
+  uint32_t band = (c->tree_two != 0 && c->tree_band >= 32) ? static_cast<uint32_t>(c->tree_band) & ~31u : 0u;
+  if (band > 128u) band = 128u;
+  {
+    const uint64_t ld = ((static_cast<uint64_t>(max_n) + 31u) & ~31ull) + 32u;
+    if ((ld * max_n + 128ull) * T_COUNT >= (1ull << 32) || max_n < 3u * band + 2u) band = 0u;
+  }
+  if (band && !c->bulk_stream) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    HIPCHK(hipStreamCreateWithPriority(&c->bulk_stream, hipStreamNonBlocking, lo));
+  }
   std::vector<TreeSeq>& tseqs = c->h_tseqs;
   tseqs.clear();
   tseqs.reserve(n_seqs);
@@ -727,7 +744,9 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
       ts.msz = ((static_cast<uint64_t>(ts.ld) * n + 63ull) & ~63ull) + 64ull;
       const uint64_t vec = (static_cast<uint64_t>(n) + 64ull + 63ull) & ~63ull;
       ts.pk_words = static_cast<uint32_t>(((static_cast<uint64_t>(n) + 160) / 16 + 4 + 63) & ~63ull);
-      const uint64_t need = ts.msz * T_COUNT + 2ull * vec + ts.pk_words;
+      // (mid-field ring: three products x 2 bands of diagonals x vec cells x {max, sum})
+      const uint64_t mid_floats = band ? 3ull * (2ull * band) * vec * 2ull : 0ull;
+      const uint64_t need = ts.msz * T_COUNT + 2ull * vec + ts.pk_words + mid_floats;
       if (cnt > 0 && (cnt >= static_cast<uint32_t>(c->group_max_seqs) ||
                       cur_nt + n > static_cast<uint64_t>(c->group_max_nt) ||
                       cur + need > ws_cap_floats)) {
@@ -740,6 +759,7 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
       ts.seq_off = offsets[s];
       ts.ws_off = cur;
       ts.pk_off = cur + ts.msz * T_COUNT + 2ull * vec;
+      ts.mid_off = ts.pk_off + ts.pk_words;
       ts.out_off = hooks ? cur_out : out_offsets[s];
       ts.batch_idx = s;
       tseqs.push_back(ts);
@@ -808,6 +828,7 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
 #ifdef RNAMC_DEBUG_KNOBS
     b.debug = static_cast<int>(c->tree_debug);
 #endif
+    b.ring = 2u * band;
     auto active = [&](uint32_t d) {  // sequences with n > d form a prefix of the group
       uint32_t lo = 0, hi = nseq;
       while (lo < hi) {
@@ -821,8 +842,100 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
     launch_tree_static(b, contra, nseq, gmax, st);
     c->stats.launches_other += 2;
     const bool two = c->tree_two != 0;
+    const uint32_t ering = static_cast<uint32_t>(c->ev_a.size());
+    if (band) {
+      // Banded sweep: launches are pairs (2m, 2m+1) (a lone first / last diagonal where the
+      // range starts odd / ends even), so no launch straddles a band [x*band, (x+1)*band).
+      // Inside: band x >= 3 takes the terms with both operand spans below thr = (x-1)*band from
+      // k_tree_mid, which needs the diagonals below thr: enqueued on bulk_stream when band
+      // x-1 starts, awaited when band x starts.  Rings: ev_a "the sweep reached a band boundary",
+      // ev_b "mid-field of the band written".
+      const uint32_t nb = (gmax + band - 1) / band;  // bands 0 .. nb-1
+      // sums_external's first row and last column (k_tree_ext) trail the sweep by one band on
+      // bulk_stream as well (the outside sweep is their only reader).
+      auto boundary = [&](uint32_t x) -> int {  // "the sweep reached band x": bulk_stream may pass
+        HIPCHK(hipEventRecord(c->ev_a[x % ering], st));
+        HIPCHK(hipStreamWaitEvent(c->bulk_stream, c->ev_a[x % ering], 0));
+        return RNAMC_OK;
+      };
+      auto enqueue_mid = [&](bool outside, uint32_t x, uint32_t thr) -> int {
+        const uint32_t dlo = x * band, dhi = std::min(gmax - 1, dlo + band - 1);
+        launch_tree_mid(b, outside, dlo, dhi, thr, gmax, active(dlo), c->bulk_stream);
+        HIPCHK(hipEventRecord(c->ev_b[x % ering], c->bulk_stream));
+        c->stats.launches_other++;
+        return RNAMC_OK;
+      };
+      auto enqueue_ext = [&](uint32_t x) {  // band x of the inside sweep is enqueued whole
+        const uint32_t dlo = std::max(dmin_in, x * band), dhi = std::min(gmax - 1, x * band + band - 1);
+        if (dlo > dhi) return;
+        launch_tree_ext(b, contra, dlo, dhi, gmax, active(dlo), c->bulk_stream);
+        c->stats.launches_other++;
+      };
+      uint32_t d = dmin_in;
+      uint32_t cur_band = ~0u;
+      while (d < gmax) {
+        const uint32_t x = d / band;
+        if (x != cur_band) {
+          // band x starts: everything below x*band is enqueued; sums_external of band x-1 and
+          // the mid-field of band x+1 can go
+          rc = boundary(x);
+          if (rc) return rc;
+          if (cur_band != ~0u) enqueue_ext(cur_band);
+          cur_band = x;
+          if (x + 1 >= 3 && x + 1 < nb) {
+            rc = enqueue_mid(false, x + 1, x * band);
+            if (rc) return rc;
+          }
+          if (x >= 3) HIPCHK(hipStreamWaitEvent(st, c->ev_b[x % ering], 0));
+        }
+        const uint32_t thr = x >= 3 ? (x - 1) * band : 0u;
+        const bool pair = (d % 2u == 0u) && d + 1 < gmax;
+        launch_tree_inside(b, contra, d, gmax, active(d), c->tree_tpc, pair, thr, st);
+        c->stats.launches_inside++;
+        d += pair ? 2 : 1;
+      }
+      if (cur_band != ~0u) {  // the last band's sums_external; the outside sweep reads them
+        rc = boundary(cur_band + 1);
+        if (rc) return rc;
+        enqueue_ext(cur_band);
+        HIPCHK(hipEventRecord(c->ev_b[(cur_band + 1) % ering], c->bulk_stream));
+        HIPCHK(hipStreamWaitEvent(st, c->ev_b[(cur_band + 1) % ering], 0));
+      }
+      if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 1], st));
+      launch_tree_init(b, nseq, gmax, contra, 1, st);
+      c->stats.launches_other++;
+      // Outside, from the top: band x takes the terms whose outside operand spans at least
+      // thr = (x+2)*band (final once band x+2 is through) from k_tree_mid, enqueued when band x+1
+      // starts.  (The first enqueue also orders bulk_stream after the inside sweep's last reads of
+      // the ring and after launch_tree_init.)
+      int64_t dd = static_cast<int64_t>(gmax) - 1;
+      cur_band = ~0u;
+      while (dd >= static_cast<int64_t>(dmin_out)) {
+        const uint32_t du = static_cast<uint32_t>(dd);
+        const uint32_t x = du / band;
+        if (x != cur_band) {
+          cur_band = x;
+          if (x >= 1 && (x + 1) * band < gmax) {  // band x-1 has a mid-field: thr = (x+1)*band <= gmax-1
+            rc = boundary(x);
+            if (rc) return rc;
+            rc = enqueue_mid(true, x - 1, (x + 1) * band);
+            if (rc) return rc;
+          }
+          if ((x + 2) * band < gmax) HIPCHK(hipStreamWaitEvent(st, c->ev_b[x % ering], 0));
+        }
+        const uint32_t thr = (x + 2) * band < gmax ? (x + 2) * band : 0u;
+        if (du % 2u == 1u && du - 1 >= dmin_out) {
+          launch_tree_outside(b, contra, du - 1, gmax, active(du - 1), c->tree_tpc, true, thr, st);
+          dd -= 2;
+        } else {
+          launch_tree_outside(b, contra, du, gmax, active(du), c->tree_tpc, false, thr, st);
+          dd -= 1;
+        }
+        c->stats.launches_outside++;
+      }
+    } else {
     for (uint32_t d = dmin_in; d < gmax; d += two ? 2 : 1) {
-      launch_tree_inside(b, contra, d, gmax, active(d), c->tree_tpc, two, st);
+      launch_tree_inside(b, contra, d, gmax, active(d), c->tree_tpc, two, 0u, st);
       c->stats.launches_inside++;
     }
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 1], st));
@@ -833,18 +946,19 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
       int64_t d = static_cast<int64_t>(gmax) - 1;
       for (; d - 1 >= static_cast<int64_t>(dmin_out); d -= 2) {
         launch_tree_outside(b, contra, static_cast<uint32_t>(d - 1), gmax, active(static_cast<uint32_t>(d - 1)),
-                            c->tree_tpc, true, st);
+                            c->tree_tpc, true, 0u, st);
         c->stats.launches_outside++;
       }
       if (d >= static_cast<int64_t>(dmin_out)) {
         launch_tree_outside(b, contra, static_cast<uint32_t>(d), gmax, active(static_cast<uint32_t>(d)),
-                            c->tree_tpc, false, st);
+                            c->tree_tpc, false, 0u, st);
         c->stats.launches_outside++;
       }
     } else
     for (uint32_t d = gmax; d-- > dmin_out;) {
-      launch_tree_outside(b, contra, d, gmax, active(d), c->tree_tpc, false, st);
+      launch_tree_outside(b, contra, d, gmax, active(d), c->tree_tpc, false, 0u, st);
       c->stats.launches_outside++;
+    }
     }
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 2], st));
     launch_tree_finalize(b, nseq, gmax, st);
@@ -1020,6 +1134,7 @@ void rnamc_ctx_destroy(rnamc_ctx* c) {
     for (hipEvent_t e : c->ev_a) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_b) (void)hipEventDestroy(e);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    if (c->bulk_stream) (void)hipStreamDestroy(c->bulk_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->st_bases) (void)hipFree(c->st_bases);
     for (int k = 0; k < 2; k++) {
@@ -1067,8 +1182,12 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     tree_policy(value, 0);
   } else if (k == "tree_short" && value >= 1) {
     tree_policy(0, value);
+  } else if (k == "tree_mid_wgs" && value >= 1) {
+    tree_mid_policy(value);
   } else if (k == "tree_two") {
     c->tree_two = value;
+  } else if (k == "tree_band" && value >= 0 && value <= 128 && value % 32 == 0) {
+    c->tree_band = value;
   } else if (k == "tree_tpc" && (value == 0 || value == 64 || value == 128 || value == 256 || value == 1024)) {
     c->tree_tpc = value;
   } else if (k == "group_max_seqs" && value >= 1) {

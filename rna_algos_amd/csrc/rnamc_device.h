@@ -119,6 +119,8 @@ struct TreeSeq {
   uint64_t pk_off;    // float offset of the 2-bit packed copy of the bases (pk_words words)
   uint32_t pk_words;
   uint32_t batch_idx;
+  uint64_t mid_off;   // float offset of the banded mid-field ring: three products x `ring`
+                      // diagonals x (n + 64 rounded up to 64) cells x {max, sum} (rnamc_tree.hip)
 };
 struct TreeBatch {
   const TreeSeq* seqs;  // descriptors of the group (device memory)
@@ -133,16 +135,26 @@ struct TreeBatch {
   const float* hp_init;
   int allows_short_hairpins;
   int debug;  // timing experiments (builds with -DRNAMC_DEBUG_KNOBS only; 0 otherwise)
+  uint32_t ring;  // diagonals the mid-field ring holds (twice the band width; 0: no banding)
 };
 // what = 0: everything before the inside sweep; 1: the four reused slots before the outside sweep
 void launch_tree_init(const TreeBatch& b, uint32_t nseq, uint32_t max_n, bool contra, int what,
                       hipStream_t st);
 // tpc_knob: threads per cell (64, 256, 1024), anything else = chosen by the diagonal's cells;
 // two: diagonals d and d+1 in one launch (inside: d then d+1; outside: d+1 then d)
+// thr: banded mid-field threshold of the launch's band (0: none; the launch's sums run whole)
 void launch_tree_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
-                        int64_t tpc_knob, bool two, hipStream_t st);
+                        int64_t tpc_knob, bool two, uint32_t thr, hipStream_t st);
 void launch_tree_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
-                         int64_t tpc_knob, bool two, hipStream_t st);
+                         int64_t tpc_knob, bool two, uint32_t thr, hipStream_t st);
+// Mid-field of the cubic products for the cells of diagonals [dlo, dhi] (one band), threshold thr:
+// inside (outside = false) sums_multibranch, outside probs_multibranch and the Q1 x R part of L_e
+void launch_tree_mid(const TreeBatch& b, bool outside, uint32_t dlo, uint32_t dhi, uint32_t thr,
+                     uint32_t max_n, uint32_t nseq, hipStream_t st);
+void tree_mid_policy(int64_t wgs);  // workgroups per k_tree_mid launch
+// sums_external's first row and last column of a banded sweep, diagonals [dlo, dhi] (in order)
+void launch_tree_ext(const TreeBatch& b, bool contra, uint32_t dlo, uint32_t dhi, uint32_t max_n,
+                     uint32_t nseq, hipStream_t st);
 // threads-per-cell policy: waves a launch may hold, sums up to which one wave per cell is taken
 void tree_policy(int64_t waves, int64_t short_terms);
 // per-cell statics (hairpin / multibranch-close / accessible scores, 2-loop sides), once per group

@@ -35,6 +35,7 @@
 // One launch per anti-diagonal and pass; blockIdx.x = cell, blockIdx.y = sequence.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 
@@ -63,6 +64,11 @@ __device__ __forceinline__ float sload(const float* p) {
 }
 __device__ __forceinline__ uint32_t sload(const uint32_t* p) {
   return *reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(reinterpret_cast<uintptr_t>(p));
+}
+__device__ __forceinline__ float2 sload2(const float2* p) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const v2f v = *reinterpret_cast<const __attribute__((address_space(4))) v2f*>(reinterpret_cast<uintptr_t>(p));
+  return make_float2(v.x, v.y);
 }
 __device__ __forceinline__ float4 sload4(const float4* p) {
   typedef float v4f __attribute__((ext_vector_type(4)));
@@ -210,6 +216,8 @@ struct TSeq {
   const uint32_t* pk;  // 2-bit packed bases, 16 per word, position p at bit 2(p+32)
   float* out;  // packed diagonal-major triangle: log bpp until k_tree_finalize
   uint32_t batch_idx;
+  float2* mid;   // banded mid-field ring: [product][d % ring][i] = {max, sum} (see k_tree_mid)
+  uint32_t vec;  // cells per ring row
 };
 
 __device__ __forceinline__ TSeq load_tseq(const TreeBatch& b, uint32_t which) {
@@ -226,6 +234,8 @@ __device__ __forceinline__ TSeq load_tseq(const TreeBatch& b, uint32_t which) {
   q.pk = reinterpret_cast<const uint32_t*>(b.workspace + sd.pk_off);
   q.out = b.out + sd.out_off;
   q.batch_idx = sd.batch_idx;
+  q.mid = reinterpret_cast<float2*>(b.workspace + sd.mid_off);
+  q.vec = (sd.n + 64u + 63u) & ~63u;
   return q;
 }
 
@@ -569,8 +579,81 @@ __device__ __forceinline__ void acc_product_2b(Acc& acc0, Acc& acc1, const float
   }
 }
 
+// The same two-cell product over the EDGE of a banded cell (see k_tree_mid): e in [0, tot),
+// idx = e (e < L) or e + jump; the first cell's stream ends at lim0l (left piece) / lim0r (right)
+template <int TPC>
+__device__ __forceinline__ void acc_product_2b_split(Acc& acc0, Acc& acc1, const float* __restrict__ A,
+                                                     const float* __restrict__ B0,
+                                                     const float* __restrict__ B1, uint32_t L, uint32_t tot,
+                                                     uint32_t jump, uint32_t lim0l, uint32_t lim0r,
+                                                     uint32_t t) {
+  for (uint32_t k = t; k < tot; k += 4u * TPC) {
+    float x0[4], x1[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t e = k + static_cast<uint32_t>(u) * TPC;
+      const bool left = e < L;
+      const uint32_t idx = left ? e : e + jump;
+      const bool v1 = e < tot;
+      const bool v0 = v1 && idx < (left ? lim0l : lim0r);
+      const float a = v1 ? A[idx] : kNegInf;
+      const float p = v0 ? B0[idx] : kNegInf;
+      const float r = v1 ? B1[idx] : kNegInf;
+      x0[u] = a + p;
+      x1[u] = a + r;
+    }
+    acc_add4(acc0, x0[0], x0[1], x0[2], x0[3]);
+    acc_add4(acc1, x1[0], x1[1], x1[2], x1[3]);
+  }
+}
+template <int TPC>
+__device__ __forceinline__ void acc_product_split(Acc& a, const float* __restrict__ A,
+                                                  const float* __restrict__ B, uint32_t L, uint32_t tot,
+                                                  uint32_t jump, uint32_t t) {
+  for (uint32_t k = t; k < tot; k += 8u * TPC) {
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const uint32_t e = k + static_cast<uint32_t>(u) * TPC;
+      const uint32_t idx = e < L ? e : e + jump;
+      x[u] = e < tot ? A[idx] + B[idx] : kNegInf;
+    }
+    acc_add4(a, x[0], x[1], x[2], x[3]);
+    acc_add4(a, x[4], x[5], x[6], x[7]);
+  }
+}
+// acc_product_2b whose second stream starts at idx = lo1
+template <int TPC>
+__device__ __forceinline__ void acc_product_2b_lo(Acc& acc0, Acc& acc1, const float* __restrict__ A,
+                                                  const float* __restrict__ B0,
+                                                  const float* __restrict__ B1, uint32_t len0,
+                                                  uint32_t len1, uint32_t lo1, uint32_t t) {
+  for (uint32_t k = t; k < len1; k += 4u * TPC) {
+    float x0[4], x1[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t ku = k + static_cast<uint32_t>(u) * TPC;
+      const float a = ku < len1 ? A[ku] : kNegInf;
+      const float p = ku < len0 ? B0[ku] : kNegInf;
+      const float r = (ku < len1 && ku >= lo1) ? B1[ku] : kNegInf;
+      x0[u] = a + p;
+      x1[u] = a + r;
+    }
+    acc_add4(acc0, x0[0], x0[1], x0[2], x0[3]);
+    acc_add4(acc1, x1[0], x1[1], x1[2], x1[3]);
+  }
+}
+__device__ __forceinline__ Acc load_mid(const TSeq& q, uint32_t ring, uint32_t prod, uint32_t d, uint32_t i) {
+  const float2 v = sload2(q.mid + (static_cast<size_t>(prod) * ring + d % ring) * q.vec + i);
+  return Acc{v.x, v.y};
+}
+
+// `thr` (inside): banded cells.  The terms of sums_multibranch(i,j) whose two operands both span
+// less than thr were summed by k_tree_mid before this band started (they need nothing of the
+// last two bands); the launch adds the rest (at most 2 (d - thr) terms: the EDGE) and merges.
 template <bool CONTRA, int TPC>
-__global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatch b, uint32_t d, int single) {
+__global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatch b, uint32_t d, int single,
+                                                                        uint32_t thr) {
   constexpr int BLOCK = TPC < 256 ? 256 : TPC;
   constexpr int NA = 9;
   __shared__ float red[BLOCK / 64][NA][2];
@@ -619,7 +702,10 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
   const float qmn = (has1 && don && d >= 2) ? sload(q.m[T_QM] + row_i + 2 * static_cast<size_t>(ld) + j) : kNegInf;  // Qm(i+2, j)
   float zr_e_prev = kNegInf, zr_m_prev = kNegInf, zr_e_prevn = kNegInf, zr_m_prevn = kNegInf;
   float u_next0 = kNegInf, u_nextn = kNegInf;  // U(i+1, j), U(i+2, j+1)
-  const bool zs0 = j == n - 1, zs1 = has1 && j1 == n - 1;  // which cell sits in column n-1
+  // (banded sweeps: sums_external's row 0 and column n-1 are k_tree_ext's, a band behind)
+  const bool ext_side = b.ring != 0u;
+  const bool zs0 = !ext_side && j == n - 1, zs1 = !ext_side && has1 && j1 == n - 1;  // which cell sits in column n-1
+  const bool row0 = !ext_side && i == 0;
   float zs_a = 0.f, zs_last = 0.f, zp1 = 0.f, q1_ii = kNegInf;
   if (w0) {
     if (j >= 1) {
@@ -632,13 +718,24 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
       if (CONTRA) zr_m_prevn = sload(q.m[T_ZRM] + col_j + i + 1);
       u_nextn = sload(q.m[T_U] + col_j + ld + i + 2);
     }
-    zs_a = zs0 ? sload(q.zs + i + 1) : (zs1 ? sload(q.zs + i + 2) : 0.f);  // Z(i+1,n-1) | Z(i+2,n-1)
-    zs_last = zs1 ? sload(q.zs + j + 1) : 0.f;                              // Z(n-1,n-1)
-    zp1 = (i == 0 && has1) ? sload(q.zp + 1) : 0.f;                         // Z(0,0)
+    if (!ext_side) {
+      zs_a = zs0 ? sload(q.zs + i + 1) : (zs1 ? sload(q.zs + i + 2) : 0.f);  // Z(i+1,n-1) | Z(i+2,n-1)
+      zs_last = zs1 ? sload(q.zs + j + 1) : 0.f;                              // Z(n-1,n-1)
+      zp1 = (i == 0 && has1) ? sload(q.zp + 1) : 0.f;                         // Z(0,0)
+    }
     // the k = i+1 term of sums_multibranch(i,j) (left out of the two-cell product below)
     if (has1 && d >= 2) q1_ii = sload(q.m[T_Q1R] + row_i + i) + sload(q.m[T_ZRM] + col_j + i + 1);
   }
   const bool act0 = mbc0 > kNegInf, act1 = mbc1 > kNegInf, actn = mbcn > kNegInf;
+#ifdef RNAMC_DEBUG_KNOBS
+  if (b.debug & 8) {  // timing: the uniform operands alone
+    const float sum = mbc0 + mbc1 + mbcn + hp0 + hp1 + hpn + accs0 + accs1 + accsn + cs0.x + in0.x + cs1.y +
+                      in1.z + csn.w + qm0 + qm1 + qmn + zr_e_prev + zr_m_prev + zr_e_prevn + zr_m_prevn +
+                      u_next0 + u_nextn + zs_a + zs_last + zp1 + q1_ii;
+    if (t == 0u && sum == 12345.f) q.zp[0] = 1.f;
+    return;
+  }
+#endif
 
   Acc acc[NA];
 #pragma unroll
@@ -659,7 +756,16 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
   if (!(b.debug & 2))
 #endif
   {
-    if (has1) {
+    if (thr != 0u) {
+      // idx: Q1(i, i+1+idx) [span idx+1] + Zr_mb(i+2+idx, j | j+1) [span d-2-idx | d-1-idx]
+      if (has1)
+        acc_product_2b_split<TPC>(acc[3], acc[4], q.m[T_Q1R] + row_i + i + 1, q.m[T_ZRM] + col_j + i + 2,
+                                  q.m[T_ZRM] + col_j + ld + i + 2, d - thr, 2u * (d - thr),
+                                  (thr - 1u) - (d - thr), d - 1u - thr, d - 2u, t);
+      else  // idx': Q1(i, i+idx') [span idx'] + Zr_mb(i+1+idx', j) [span d-1-idx']
+        acc_product_split<TPC>(acc[3], q.m[T_Q1R] + row_i + i, q.m[T_ZRM] + col_j + i + 1, d - thr,
+                               (d - thr) + (d - 1u - thr), thr - (d - thr), t);
+    } else if (has1) {
       if (d >= 2)
         acc_product_2b<TPC>(acc[3], acc[4], q.m[T_Q1R] + row_i + i + 1, q.m[T_ZRM] + col_j + i + 2,
                             q.m[T_ZRM] + col_j + ld + i + 2, d - 2, d - 1, t);
@@ -668,7 +774,7 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
       acc_product<TPC>(acc[3], q.m[T_Q1R] + row_i + i, q.m[T_ZRM] + col_j + i + 1, d - 1, t);
     }
     // [5] [6] Z(0,j), Z(0,j+1): k >= 1 | 2, Zr_ext(k,.) + Z(0,k-1)
-    if (i == 0) {
+    if (row0) {
       if (j >= 1) acc_product<TPC>(acc[5], q.m[T_ZRE] + col_j + 1, q.zp + 1, j, t);
       if (has1 && j1 >= 2) acc_product<TPC>(acc[6], q.m[T_ZRE] + col_j + ld + 2, q.zp + 2, j1 - 1, t);
     }
@@ -680,8 +786,16 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
       acc_product<TPC>(acc[8], q.m[T_QA] + row_i + ld + i + 2, q.zs + i + 3, d - 1, t);
   }
   if (t == 0u) acc_add(acc[3], q1_ii);
+  if (thr != 0u && w0) {
+    const Acc m0 = load_mid(q, b.ring, 0u, d, i);
+    const Acc m1 = has1 ? load_mid(q, b.ring, 0u, d + 1u, i) : acc_empty();
+    if (t == 0u) {
+      acc_merge(acc[3], m0);
+      acc_merge(acc[4], m1);
+    }
+  }
   // (the sums_external accumulators [5..8] live only in row 0 and in the column n-1 groups)
-  if (!cell_reduce<NA, TPC>(acc, red, (i == 0 || zs0 || zs1) ? NA : 5)) return;
+  if (!cell_reduce<NA, TPC>(acc, red, (row0 || zs0 || zs1) ? NA : 5)) return;
 #ifdef RNAMC_DEBUG_KNOBS
   if (b.debug & 16) {  // timing: no epilogue
     if (t == 0u && acc[0].s + acc[1].s + acc[2].s + acc[3].s + acc[4].s == 12345.f) q.zp[0] = 1.f;
@@ -722,7 +836,7 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
     q.m[T_Q1R][row_i + j] = q1_0;
     q.m[T_Q1C][col_j + i] = q1_0;
   }
-  if (i == 0) {
+  if (row0) {
     // sums_external[0][j] (352-363 / 487-498)
     Acc z = acc[5];
     acc_add(z, zr_e0);  // k = 0: Z(0,-1) = 0
@@ -773,7 +887,7 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
     q.m[T_Q1R][row_i + j1] = q1_1;
     q.m[T_Q1C][col_j1 + i] = q1_1;
   }
-  if (i == 0) {
+  if (row0) {
     Acc z = acc[6];
     acc_add(z, zr_e1);        // k = 0
     acc_add(z, zr_en + zp1);  // k = 1: Zr_ext(1,j+1) + Z(0,0)
@@ -806,8 +920,9 @@ __device__ __forceinline__ void acc_product_3(Acc& pm0, Acc& pmn, Acc& pm1,
                                               const float* __restrict__ Wi,
                                               const float* __restrict__ Wm,
                                               const float* __restrict__ Qa,
-                                              const float* __restrict__ Qb, uint32_t len0, bool do_n,
-                                              bool do_1, uint32_t t) {
+                                              const float* __restrict__ Qb, uint32_t len0,
+                                              uint32_t lenn, bool do_n, bool do_1, uint32_t t) {
+  // (lenn <= len0: where the neighbour's stream ends)
   for (uint32_t k = t; k < len0; k += 4u * TPC) {
     float x0[4], xn[4], x1[4];
 #pragma unroll
@@ -815,7 +930,7 @@ __device__ __forceinline__ void acc_product_3(Acc& pm0, Acc& pmn, Acc& pm1,
       const uint32_t ku = k + static_cast<uint32_t>(u) * TPC;
       const bool v = ku < len0;
       const float wi = v ? Wi[ku] : kNegInf;
-      const float wm = (v && do_n) ? Wm[ku] : kNegInf;
+      const float wm = (ku < lenn && do_n) ? Wm[ku] : kNegInf;
       const float qa = v ? Qa[ku] : kNegInf;
       const float qb = (v && do_1 && ku >= 1u) ? Qb[ku] : kNegInf;
       x0[u] = wi + qa;
@@ -829,8 +944,12 @@ __device__ __forceinline__ void acc_product_3(Acc& pm0, Acc& pmn, Acc& pm1,
 }
 
 // diagonals d+1 (cell (i,j+1)) and d (cell (i,j)) of the outside sweep
+// `thr` (outside): banded cells.  The terms of probs_multibranch and of L_e (cases one / three)
+// whose OUTSIDE operand (W(i,k), R(k,j)) spans at least thr were summed by k_tree_mid before
+// the band above this one started; the launch adds the nearer ones and merges.
 template <bool CONTRA, int TPC>
-__global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBatch b, uint32_t d, int single) {
+__global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBatch b, uint32_t d, int single,
+                                                                         uint32_t thr) {
   constexpr int BLOCK = TPC < 256 ? 256 : TPC;
   constexpr int NA = 7;
   __shared__ float red[BLOCK / 64][NA][2];
@@ -907,17 +1026,41 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBat
   if (!(b.debug & 2))
 #endif
   {
-    if (n - 1 - j >= 2)
+    if (n - 1 - j >= 2) {
+      // idx: W(i | i-1, j+1+idx) [span d+1+idx | d+2+idx]: the launch's part ends below span thr
+      const uint32_t len0 = n - 1 - j;
+      const uint32_t lim0 = thr != 0u ? min(len0, thr - 1u - d) : len0;
+      const uint32_t limn = thr != 0u ? min(len0, thr - 2u - d) : len0;
       acc_product_3<TPC>(acc[0], acc[1], acc[2], w_r + row_i + j1, w_r + row_i - ld + j1,
                          q.m[T_Q1R] + static_cast<size_t>(j1) * ld + j,
-                         q.m[T_Q1R] + static_cast<size_t>(j1 + 1) * ld + j, n - 1 - j, i >= 1, has1, t);
+                         q.m[T_Q1R] + static_cast<size_t>(j1 + 1) * ld + j, lim0, limn, i >= 1, has1, t);
+    }
     // [5] [6] L_e cases one and three of (i,j) and (i,j+1): k = 0 .. i-1, Q1(k+1,i-1) + R(k,.)
+    // (banded: R(k, j | j+1) of span below thr, k >= j - thr + 1 | j - thr + 2)
     if (i >= 1 && (paired0 || paired1)) {
+      const uint32_t base = (thr != 0u && j + 1u > thr) ? j + 1u - thr : 0u;
+      const uint32_t lo1 = (thr != 0u && j + 1u >= thr) ? 1u : 0u;
+      const float* __restrict__ A = q.m[T_Q1C] + static_cast<size_t>(i - 1) * ld + 1 + base;
       if (has1)
-        acc_product_2b<TPC>(acc[5], acc[6], q.m[T_Q1C] + static_cast<size_t>(i - 1) * ld + 1, r_c + col_j,
-                            r_c + col_j + ld, i - 1, i, t);
+        acc_product_2b_lo<TPC>(acc[5], acc[6], A, r_c + col_j + base, r_c + col_j + ld + base,
+                               i - 1 - base, i - base, lo1, t);
       else
-        acc_product<TPC>(acc[5], q.m[T_Q1C] + static_cast<size_t>(i - 1) * ld + 1, r_c + col_j, i - 1, t);
+        acc_product<TPC>(acc[5], A, r_c + col_j + base, i - 1 - base, t);
+    }
+  }
+  if (thr != 0u && w0) {
+    // (the ring rows of diagonals d, d+1 belong to this band; cells past the matrix are never read)
+    const Acc p0 = load_mid(q, b.ring, 1u, d, i);
+    const Acc pn = (i >= 1 && j < n - 1) ? load_mid(q, b.ring, 1u, d + 1u, i - 1u) : acc_empty();
+    const Acc p1 = has1 ? load_mid(q, b.ring, 1u, d + 1u, i) : acc_empty();
+    const Acc e0 = load_mid(q, b.ring, 2u, d, i);
+    const Acc e1 = has1 ? load_mid(q, b.ring, 2u, d + 1u, i) : acc_empty();
+    if (t == 0u) {
+      acc_merge(acc[0], p0);
+      acc_merge(acc[1], pn);
+      acc_merge(acc[2], p1);
+      acc_merge(acc[5], e0);
+      acc_merge(acc[6], e1);
     }
   }
   if (!cell_reduce<NA, TPC>(acc, red)) return;
@@ -988,6 +1131,289 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBat
   }
 }
 
+// ----------------------------------------------------------------------------
+// Banded mid-field of the cubic products.  A launch of the sweep is a chain of dependent round
+// trips, and a cell's product walks d terms of it; but of the d terms of sums_multibranch(i,j)
+// only those with an operand from the last two BANDS of diagonals (band = kBand diagonals) depend
+// on recent launches.  All others — both operands of span below thr = (band - 1) * width (inside),
+// resp. the outside operand of span at least thr = (band + 2) * width (outside) — are final one
+// whole band before the cell's own launch.  k_tree_mid sums them for every cell of a band as
+// a tiled (logsumexp,+) matrix product on a second stream while the previous band sweeps: the
+// operands of an 8 x 32 tile of cells (rows i, diagonals d) are staged through LDS in pieces of 16
+// k and every lane folds four cells (one row, four diagonals) off them (a term costs ~10 VALU
+// slots and 5 B of LDS reads, no HBM round trip).  The sweep's launches then walk at most 4 band
+// widths of terms per product and merge the cell's {max, sum} pair from the ring.
+//   prod 0 (inside)  C(i,j) = (+)_{k = j-thr+1 .. i+thr}  Q1(i,k-1) + Zr_mb(k,j)
+//   prod 1 (outside) C(i,j) = (+)_{k = i+thr .. n-1}      W(i,k)    + Q1(j+1,k-1)
+//   prod 2 (outside) C(i,j) = (+)_{k = 0 .. j-thr}        Q1(k+1,i-1) + R(k,j)
+// A workgroup is eight waves = eight interleaved sets of k pieces of ONE tile, merged through LDS
+// at the end (fixed order: results are deterministic).
+constexpr int kMidTI = 8, kMidTD = 32, kMidKC = 16, kMidRow = 20, kMidWaves = 8;
+constexpr int kMidRows = kMidTI + kMidTI + kMidTD - 1;  // 8 A rows + 39 B columns
+constexpr int kMidPf = (kMidRows * kMidKC + 63) / 64;   // staged elements per lane and piece
+
+// (at most 84 VGPRs: six waves per SIMD, so that the sweep's launches, ~85 VGPRs, keep four of
+// their five waves per SIMD while a mid-field kernel is resident)
+__global__ void __launch_bounds__(64 * kMidWaves) __attribute__((amdgpu_waves_per_eu(6, 6)))
+k_tree_mid(TreeBatch b, uint32_t dlo, uint32_t dhi, uint32_t thr, int outside, uint32_t tiles_i,
+           uint32_t tiles_z) {
+  __shared__ float stage[kMidWaves][(kMidRows + 1) * kMidRow];
+  const TSeq q = load_tseq(b, blockIdx.y);
+  const int n = static_cast<int>(q.n), ld = static_cast<int>(q.ld);
+  // a fixed number of workgroups walks the band's tiles (the grid holds about two waves per
+  // SIMD, whatever the band's size: the sweep's launches keep the rest of the chip)
+  for (uint32_t tile = blockIdx.x; tile < tiles_i * tiles_z; tile += gridDim.x) {
+  const uint32_t tz = tile / tiles_i, tx = tile % tiles_i;
+  const int prod = outside ? 1 + static_cast<int>(tz & 1u) : 0;
+  const int d0 = static_cast<int>(dlo) + kMidTD * static_cast<int>(outside ? tz >> 1 : tz);
+  const int i0 = kMidTI * static_cast<int>(tx);
+  const int dtop = min(static_cast<int>(dhi), n - 1);
+  if (d0 > dtop || i0 + d0 >= n) continue;  // (uniform: no cell of this tile exists)
+  const int T = static_cast<int>(thr);
+  const int wave = static_cast<int>(threadIdx.x >> 6), lane = static_cast<int>(threadIdx.x & 63u);
+  const int li = lane & 7, lg = lane >> 3;
+
+  // operand rows as float offsets from the sequence's first matrix (< 2^32: checked by the host)
+  const float* __restrict__ base = q.m[0];
+  const uint32_t msz = static_cast<uint32_t>(q.m[1] - q.m[0]);
+  uint32_t offA, offB;  // row i0 of A / column (i0 + d0) of B, at k = 0
+  int kmin;             // smallest k whose operands exist
+  if (prod == 0) {
+    offA = T_Q1R * msz + static_cast<uint32_t>(i0) * ld - 1u;
+    offB = T_ZRM * msz + static_cast<uint32_t>(i0 + d0) * ld;
+    kmin = 1;
+  } else if (prod == 1) {
+    offA = T_ZRE * msz + static_cast<uint32_t>(i0) * ld;
+    offB = T_Q1R * msz + static_cast<uint32_t>(i0 + d0 + 1) * ld - 1u;
+    kmin = 1;
+  } else {
+    offA = T_Q1C * msz + static_cast<uint32_t>(i0 - 1) * ld + 1u;  // (row i0 - 1; i0 = 0: masked below)
+    offB = T_ZRM * msz + static_cast<uint32_t>(i0 + d0) * ld;
+    kmin = 0;
+  }
+  // rows of the stage that exist: A row r <-> i = i0 + r, B row r <-> j = i0 + d0 + r
+  uint64_t rowmask = 0;
+  for (int r = 0; r < kMidTI; r++) {
+    const int i = i0 + r;
+    if (i < n && (prod != 2 || i >= 1)) rowmask |= 1ull << r;
+  }
+  for (int r = 0; r < kMidTI + kMidTD - 1; r++) {
+    const int j = i0 + d0 + r;
+    if (prod == 1 ? j + 1 < n : j < n) rowmask |= 1ull << (kMidTI + r);
+  }
+  // the tile's k range, and the part of it every cell of the tile takes whole
+  int klo, khi, ilo, ihi;
+  if (prod == 0) {
+    klo = i0 + d0 - T + 1;
+    khi = i0 + kMidTI - 1 + T;
+    ilo = (i0 + kMidTI - 1) + (d0 + kMidTD - 1) - T + 1;
+    ihi = i0 + T;
+  } else if (prod == 1) {
+    klo = i0 + T;
+    khi = n - 1;
+    ilo = i0 + kMidTI - 1 + T;
+    ihi = n - 1;
+  } else {
+    klo = 0;
+    khi = (i0 + kMidTI - 1) + (d0 + kMidTD - 1) - T;
+    ilo = 0;
+    ihi = i0 + d0 - T;
+  }
+  klo = max(klo, kmin);
+  khi = min(khi, n - 1);
+
+  // the lane's cells: row i0 + li, diagonals d0 + lg + 8 c (c < 4); B column li + lg + 8 c
+  const int ci = i0 + li;
+  Acc acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) acc[c] = acc_empty();
+
+  float* __restrict__ st = stage[wave];
+  const int nch = klo <= khi ? (khi - klo) / kMidKC + 1 : 0;
+  // piece `ch` of the operands into registers: element e = lane + 64 u <-> row e / 16, k e % 16;
+  // rows 4u .. 4u+3 are A rows for u < kMidTI / 4, B columns beyond: lane part + uniform part
+  const uint32_t lrow = static_cast<uint32_t>(lane) >> 4, lk = static_cast<uint32_t>(lane) & 15u;
+  const uint32_t vA = offA + lrow * static_cast<uint32_t>(ld) + lk;
+  const uint32_t vB = offB + lrow * static_cast<uint32_t>(ld) + lk;
+  uint32_t lmask = 0;  // bit u: the lane's row of step u exists
+#pragma unroll
+  for (int u = 0; u < kMidPf; u++) {
+    const uint32_t row = lrow + 4u * u;
+    if (row < kMidRows && ((rowmask >> row) & 1ull) != 0ull) lmask |= 1u << u;
+  }
+  float pf[kMidPf];
+  auto fetch = [&](int ch) {
+    const uint32_t kk = static_cast<uint32_t>(klo + ch * kMidKC);  // (uniform)
+#pragma unroll
+    for (int u = 0; u < kMidPf; u++) {
+      const uint32_t uni = (u < kMidTI / 4 ? 4u * u : 4u * (u - kMidTI / 4)) * static_cast<uint32_t>(ld) + kk;
+      const uint32_t off = (u < kMidTI / 4 ? vA : vB) + uni;
+      pf[u] = ((lmask >> u) & 1u) ? base[off] : kNegInf;
+    }
+  };
+  if (wave < nch) fetch(wave);
+  for (int ch = wave; ch < nch; ch += kMidWaves) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < kMidPf; u++) {
+      const int row = (lane >> 4) + 4 * u;  // (the stage has room for row kMidRows too)
+      st[row * kMidRow + (lane & 15)] = pf[u];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (ch + kMidWaves < nch) fetch(ch + kMidWaves);
+    const int kc = klo + ch * kMidKC;
+    const bool whole = kc >= ilo && kc + kMidKC - 1 <= ihi;  // (uniform)
+    if (whole) {
+#pragma unroll 1
+      for (int k4 = 0; k4 < kMidKC / 4; k4++) {
+        const float4 a = *reinterpret_cast<const float4*>(st + li * kMidRow + 4 * k4);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const float4 bq = *reinterpret_cast<const float4*>(st + (kMidTI + li + lg + 8 * c) * kMidRow + 4 * k4);
+          acc_add4(acc[c], a.x + bq.x, a.y + bq.y, a.z + bq.z, a.w + bq.w);
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int k4 = 0; k4 < kMidKC / 4; k4++) {
+        const float4 a = *reinterpret_cast<const float4*>(st + li * kMidRow + 4 * k4);
+        const int k = kc + 4 * k4;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const float4 bq = *reinterpret_cast<const float4*>(st + (kMidTI + li + lg + 8 * c) * kMidRow + 4 * k4);
+          // the cell's own k range as (first k, last k - first k); no terms: (2^30, 0)
+          const int d = d0 + lg + 8 * c, j = ci + d;
+          int lo = prod == 0 ? j - T + 1 : (prod == 1 ? ci + T : 0);
+          const int hi = prod == 0 ? ci + T : (prod == 1 ? n - 1 : j - T);
+          lo = max(lo, kmin);
+          const bool ok = d <= dtop && j < n && lo <= hi;
+          const uint32_t rel = static_cast<uint32_t>(k - (ok ? lo : (1 << 30)));
+          const uint32_t len = ok ? static_cast<uint32_t>(hi - lo) : 0u;
+          const float x0 = rel <= len ? a.x + bq.x : kNegInf;
+          const float x1 = rel + 1u <= len ? a.y + bq.y : kNegInf;
+          const float x2 = rel + 2u <= len ? a.z + bq.z : kNegInf;
+          const float x3 = rel + 3u <= len ? a.w + bq.w : kNegInf;
+          acc_add4(acc[c], x0, x1, x2, x3);
+        }
+      }
+    }
+  }
+  // merge the eight waves' partial sums: wave w, lanes 32 (w & 1) .. + 31 fold register cell
+  // w >> 1 of the 64 lanes' cells, two threads per ... (kept simple: waves 0..3 fold one cell each)
+  __syncthreads();
+  float* __restrict__ red = &stage[0][0];  // [wave][cell][lane][2]: 8 * 4 * 64 * 2 floats = 16 KB
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    float* p = red + ((wave * 4 + c) * 64 + lane) * 2;
+    p[0] = acc[c].m;
+    p[1] = acc[c].s;
+  }
+  __syncthreads();
+  if (wave < 4) {
+    Acc tot = acc_empty();
+#pragma unroll
+    for (int w = 0; w < kMidWaves; w++) {
+      const float* p = red + ((w * 4 + wave) * 64 + lane) * 2;
+      acc_merge(tot, Acc{p[0], p[1]});
+    }
+    const int d = d0 + lg + 8 * wave;
+    if (d <= dtop && ci + d < n)
+      q.mid[(static_cast<size_t>(prod) * b.ring + static_cast<uint32_t>(d) % b.ring) * q.vec + ci] =
+          make_float2(tot.m, tot.s);
+  }
+  __syncthreads();  // (the next tile's pieces overwrite the exchange area)
+  }
+}
+
+// sums_external of a banded sweep: its first row Z(0,j) (prefix vector zp; 352-363 / 487-498)
+// and last column Z(i,n-1) (suffix vector zs, leftmost-pair decomposition) are read by the
+// outside sweep only, and step d of either needs just diagonal d of the inside sweep.  Inside a
+// launch each is ONE cell with a sum of d terms — the longest chain of the launch once the products
+// are banded.  This kernel walks them a band behind the sweep instead, beside it: workgroup 0 the
+// row, workgroup 1 the column, one step per diagonal d in [dlo, dhi], 1024 lanes per sum, the vector
+// in LDS, the matrix operand of the next step in flight while this one is reduced.
+//   zp[j+1] = (+)_{k=0..j} (Zr_ext(k,j) + zp[k])  (+)  unpaired          (j = d; zp[0] = 0)
+//   zs[i]   = ((+)_{l=i+1..n-1} Qa(i,l) + zs[l+1]) + ext_bp  (+)  (zs[i+1] + ext_un)   (i = n-1-d)
+template <bool CONTRA>
+__global__ void __launch_bounds__(1024) k_tree_ext(TreeBatch b, uint32_t dlo, uint32_t dhi) {
+  extern __shared__ float vec[];  // zp[0 .. n] | zs[0 .. n] shifted so that the walk reads vec[k]
+  __shared__ float red[16][2];
+  const TSeq q = load_tseq(b, blockIdx.y);
+  const uint32_t n = q.n, ld = q.ld;
+  if (dlo >= n) return;
+  const uint32_t dtop = min(dhi, n - 1u);
+  const bool col = blockIdx.x == 1u;
+  const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63u;
+  const float ext_bp = CONTRA ? b.params->contra.external_score_basepair : 0.f;
+  const float ext_un = CONTRA ? b.params->contra.external_score_unpair : 0.f;
+  // row: vec[k] = zp[k]; column: vec[x] = zs[x] (the walk of step i reads vec[l+1])
+  float* __restrict__ gv = col ? q.zs : q.zp;
+  for (uint32_t x = t; x <= n; x += 1024u) vec[x] = gv[x];
+  __syncthreads();
+  // operand of step d: row: ZRE[j*ld + k], k = 0..j (j = d); column: QA[i*ld + l], l = i+1..n-1
+  auto operand = [&](uint32_t d) -> const float* {
+    return col ? q.m[T_QA] + static_cast<size_t>(n - 1u - d) * ld + (n - d)  // l = i+1 at index 0
+               : q.m[T_ZRE] + static_cast<size_t>(d) * ld;
+  };
+  auto terms = [&](uint32_t d) { return col ? d : d + 1u; };
+  float pf[4];
+  {
+    const float* __restrict__ op = operand(dlo);
+    const uint32_t len = terms(dlo);
+#pragma unroll
+    for (int u = 0; u < 4; u++) pf[u] = t + 1024u * u < len ? op[t + 1024u * u] : kNegInf;
+  }
+  for (uint32_t d = dlo; d <= dtop; d++) {
+    const float* __restrict__ op = operand(d);
+    const uint32_t len = terms(d);
+    const uint32_t i = n - 1u - d;
+    // row: term k pairs with vec[k]; column: term idx (l = i+1+idx) with vec[l+1] = vec[i+2+idx]
+    const uint32_t vo = col ? i + 2u : 0u;
+    float x[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t k = t + 1024u * u;
+      x[u] = k < len ? pf[u] + vec[vo + k] : kNegInf;
+    }
+    Acc a = acc_empty();
+    acc_add4(a, x[0], x[1], x[2], x[3]);
+    for (uint32_t k = t + 4096u; k < len; k += 1024u) acc_add(a, op[k] + vec[vo + k]);
+    if (d < dtop) {  // the next step's operand (final data: independent of this step's result)
+      const float* __restrict__ opn = operand(d + 1u);
+      const uint32_t lenn = terms(d + 1u);
+#pragma unroll
+      for (int u = 0; u < 4; u++) pf[u] = t + 1024u * u < lenn ? opn[t + 1024u * u] : kNegInf;
+    }
+    a = wave_reduce(a);
+    if (lane == 0u) {
+      red[wave][0] = a.m;
+      red[wave][1] = a.s;
+    }
+    __syncthreads();
+    if (wave == 0u) {
+      Acc z = lane < 16u ? Acc{red[lane][0], red[lane][1]} : acc_empty();
+      z = wave_reduce(z);
+      if (lane == 0u) {
+        float v;
+        if (col) {
+          z.m += ext_bp;
+          acc_add(z, vec[i + 1u] + ext_un);
+          v = acc_value(z);
+          vec[i] = v;
+          q.zs[i] = v;
+        } else {
+          acc_add(z, CONTRA ? ext_un * static_cast<float>(d + 1u) : 0.f);
+          v = acc_value(z);
+          vec[d + 1u] = v;
+          q.zp[d + 1u] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void __launch_bounds__(256) k_tree_finalize(TreeBatch b) {
   const TreeSeq sd = b.use_one ? b.one : b.seqs[blockIdx.y];
   float* out = b.out + sd.out_off;
@@ -1015,7 +1441,7 @@ void launch_tree_init(const TreeBatch& b, uint32_t nseq, uint32_t max_n, bool co
 
 #define RNAMC_TREE_LAUNCH(K, C, T)                                                              \
   hipLaunchKernelGGL((K<C, T>), dim3((cells + (T < 256 ? 256 / T : 1) - 1) / (T < 256 ? 256 / T : 1), nseq, 1), \
-                     dim3(T < 256 ? 256 : T), 0, st, b, d, two ? 0 : 1)
+                     dim3(T < 256 ? 256 : T), 0, st, b, d, two ? 0 : 1, thr)
 // Threads per cell by the length of a cell's sums (`terms`) and the number of cells: a cell's
 // lanes walk its sums four steps per stream at a time, so `terms / (4 * threads)` dependent
 // round trips set the launch's duration; more threads per cell while the chip has room for them.
@@ -1048,9 +1474,10 @@ void launch_tree_static(const TreeBatch& b, bool contra, uint32_t nseq, uint32_t
 }
 
 void launch_tree_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
-                        int64_t tpc_knob, bool two, hipStream_t st) {
+                        int64_t tpc_knob, bool two, uint32_t thr, hipStream_t st) {
   const uint32_t cells = max_n - d;
-  const int tpc = tree_tpc(static_cast<uint64_t>(cells) * nseq, d, tpc_knob);
+  // (banded: a cell's product is its edge, at most 2 (d + 1 - thr) terms)
+  const int tpc = tree_tpc(static_cast<uint64_t>(cells) * nseq, thr ? 2u * (d + 1u - thr) : d, tpc_knob);
   if (contra) {
     if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_inside2, true, 64);
     else if (tpc == 128) RNAMC_TREE_LAUNCH(k_tree_inside2, true, 128);
@@ -1065,9 +1492,10 @@ void launch_tree_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t ma
 }
 
 void launch_tree_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
-                         int64_t tpc_knob, bool two, hipStream_t st) {
+                         int64_t tpc_knob, bool two, uint32_t thr, hipStream_t st) {
   const uint32_t cells = max_n - d;
-  const int tpc = tree_tpc(static_cast<uint64_t>(cells) * nseq, max_n - d, tpc_knob);
+  const int tpc = tree_tpc(static_cast<uint64_t>(cells) * nseq, thr ? std::min(max_n - d, thr - d) : max_n - d,
+                           tpc_knob);
   if (contra) {
     if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_outside2, true, 64);
     else if (tpc == 128) RNAMC_TREE_LAUNCH(k_tree_outside2, true, 128);
@@ -1080,6 +1508,30 @@ void launch_tree_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t m
     else RNAMC_TREE_LAUNCH(k_tree_outside2, false, 1024);
   }
 #undef RNAMC_TREE_LAUNCH
+}
+
+static uint32_t g_tree_mid_wgs = 256;  // workgroups of a k_tree_mid launch (rnamc_ctx_set "tree_mid_wgs")
+void tree_mid_policy(int64_t wgs) {
+  if (wgs > 0) g_tree_mid_wgs = static_cast<uint32_t>(wgs);
+}
+void launch_tree_mid(const TreeBatch& b, bool outside, uint32_t dlo, uint32_t dhi, uint32_t thr,
+                     uint32_t max_n, uint32_t nseq, hipStream_t st) {
+  if (dlo >= max_n || dhi < dlo || nseq == 0) return;
+  const uint32_t tiles_i = (max_n - dlo + kMidTI - 1) / kMidTI;
+  const uint32_t tiles_z = ((dhi - dlo) / kMidTD + 1) * (outside ? 2u : 1u);
+  const uint32_t gx = std::max(1u, std::min(tiles_i * tiles_z, (g_tree_mid_wgs + nseq - 1) / nseq));
+  hipLaunchKernelGGL(k_tree_mid, dim3(gx, nseq, 1), dim3(64 * kMidWaves), 0, st, b, dlo, dhi, thr,
+                     outside ? 1 : 0, tiles_i, tiles_z);
+}
+
+void launch_tree_ext(const TreeBatch& b, bool contra, uint32_t dlo, uint32_t dhi, uint32_t max_n,
+                     uint32_t nseq, hipStream_t st) {
+  if (dlo >= max_n || dhi < dlo || nseq == 0) return;
+  const size_t lds = (static_cast<size_t>(max_n) + 2u) * sizeof(float);  // (< 64 KB: banding's n limit)
+  if (contra)
+    hipLaunchKernelGGL(k_tree_ext<true>, dim3(2, nseq, 1), dim3(1024), lds, st, b, dlo, dhi);
+  else
+    hipLaunchKernelGGL(k_tree_ext<false>, dim3(2, nseq, 1), dim3(1024), lds, st, b, dlo, dhi);
 }
 
 void launch_tree_finalize(const TreeBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st) {

@@ -41,7 +41,7 @@ def run(ctx, seqs, contra, short, mode, **knobs):
     finally:
         ctx.set("summation_mode", 0)
         for k in knobs:
-            ctx.set(k, {"tree_two": 1, "tree_tpc": 0}[k])
+            ctx.set(k, {"tree_two": 1, "tree_tpc": 0, "tree_band": 32}[k])
 
 
 def deviation(a, b):
@@ -157,6 +157,36 @@ def test_tree_kernel_variants_agree(ctx, params, contra, short):
             else:
                 for s, a, b0 in zip(seqs, m, base):
                     assert deviation(a.packed, b0.packed)[1] <= 2 * (2e-5 + 2e-7 * len(s))
+
+
+@pytest.mark.parametrize("contra,short", VARIANTS)
+def test_tree_banded_mid_field(ctx, params, contra, short):
+    """Banded sweep (k_tree_mid sums the mid-field of the three cubic products one band ahead on a
+    second stream, the launches add the edge) against the unbanded sweep of the same mode: the
+    same terms in another grouping — equal to f32 rounding; lone sequences and a ragged group,
+    band widths 32 and 64, lengths around the first banded diagonal (3 * band) and band ends."""
+    lens = (95, 96, 97, 98, 127, 128, 129, 130, 191, 192, 193, 200, 257, 300, 383, 410, 640)
+    seqs = [O.splitmix_seq(n, 13 * n + 5) for n in lens]
+    base, zbase = run(ctx, seqs, contra, short, 1, tree_band=0)
+    tol = lambda n: 2 * (2e-5 + 2e-7 * n)
+    for band in (32, 64):
+        m, z = run(ctx, seqs, contra, short, 1, tree_band=band)
+        for s, a, b0, za, zb in zip(seqs, m, base, z, zbase):
+            same, dp = deviation(a.packed, b0.packed)
+            assert same and dp <= tol(len(s)), (band, len(s), dp)
+            assert abs(float(za) - float(zb)) <= 3e-6 * max(1.0, abs(float(zb))), (band, len(s))
+        for x in (7, 13, 16):  # alone: other launch shapes (no ragged prefix)
+            m1, z1 = run(ctx, [seqs[x]], contra, short, 1, tree_band=band)
+            same, dp = deviation(m1[0].packed, base[x].packed)
+            assert same and dp <= tol(len(seqs[x])), (band, len(seqs[x]), dp)
+    # against the exact f64 evaluation too (the bound of test_tree_kernel_variants_agree)
+    m, z = run(ctx, [seqs[15]], contra, short, 1, tree_band=32)
+    xb, xz = O.exact_bpp(params.ptr, seqs[15], contra, short)
+    same, dt = deviation(m[0].packed, xb)
+    assert same and dt <= 2e-5 + 2e-7 * 410 and abs(float(z[0]) - xz) <= 2e-5 + 3e-6 * abs(xz)
+    # deterministic run to run (fixed merge order of the eight waves of a tile)
+    m2, z2 = run(ctx, [seqs[15]], contra, short, 1, tree_band=32)
+    assert np.array_equal(np.asarray(m2[0].packed), np.asarray(m[0].packed))
 
 
 def test_tree_ragged_batch_and_lone_calls(ctx, params):
