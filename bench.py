@@ -139,22 +139,27 @@ def pmc_traffic_per_launch(kernel, total_T, launches, contra=False):
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz: f32 VALU issue slots / s
 
 
-def tree_bytes(n, f, contra):
+def tree_bytes(n, f, contra, band=64):
     """Bytes of one n-nt sequence in tree-order mode, two ways: SURVEY 8d's streamed-operand
     model of the REFERENCE's loops (the contract's figure) and what the tree-order kernels'
-    loads name (two anti-diagonals per launch)."""
+    loads name (banded sweep, two anti-diagonals per launch)."""
     from rna_algos_amd import workloads as W
     T = float(W.pair_cost(n))
     n2h = n * n / 2.0
     b_8d = float(W.algorithmic_bytes([n], contra, f))
     either = 1.0 - (1.0 - f) ** 2  # a launch's cell pair runs L_e when either cell is a pair
-    # products: 3 loads per 2 terms inside (one row stream for two cells), 4 streams per cell pair
-    # for probs_multibranch incl. the neighbour's, 3 per 2 terms for L_e; one 16-byte gather per
-    # generic 2-loop (the neighbour's block is evaluated twice inside); dense stores
-    inside = 6.0 * T + 16.0 * 496.0 * f * n2h * 1.5 + 12 * 4.0 * n2h
-    outside = 8.0 * T + 6.0 * either * T + 16.0 * 496.0 * f * n2h + 10 * 4.0 * n2h
-    # issue slots: 8.5 per product term (add, max, exp2 = 2 slots, fma ...), ~45 per 2-loop probe
-    valu = 8.5 * T * (1.0 + 1.5 + either) + 45.0 * 496.0 * f * n2h * 2.5
+    # cubic products: the mid-field goes through k_tree_mid's LDS tiles (47 operand rows of 16 k
+    # staged per 256 cells x 16 k: 0.73 B per term); the launches walk the edge, on average
+    # 3 band widths of terms per product and cell pair (3 loads per 2 terms inside and for L_e,
+    # 4 streams per cell pair for probs_multibranch incl. the neighbour's); one 16-byte gather per
+    # generic 2-loop (the neighbour's block is evaluated twice inside); dense stores; the two
+    # sums_external vectors walk n^2 / 2 terms each (k_tree_ext)
+    staged = 47.0 * 16 * 4 / (256 * 16)
+    edge = 3.0 * band * n2h / 2.0  # terms walked per product by the launches (per cell PAIR: n2h / 2 pairs)
+    inside = staged * T + 12.0 * edge + 16.0 * 496.0 * f * n2h * 1.5 + 12 * 4.0 * n2h + 2 * 4.0 * n2h
+    outside = staged * T * (1.0 + either) + (16.0 + 12.0 * either) * edge + 16.0 * 496.0 * f * n2h + 10 * 4.0 * n2h
+    # issue slots: ~10 per product term (add, max, fma, exp2 at quarter rate ...), ~45 per 2-loop probe
+    valu = 10.0 * T * (1.0 + 1.0 + either) + 45.0 * 496.0 * f * n2h * 2.5
     return {"b_8d": b_8d, "inside": inside, "outside": outside, "valu_slots": valu}
 
 
@@ -190,7 +195,8 @@ def tree_leg(ctx, torch, dev, stream, seq, contra, reps, f, ref=None):
         "summation": "tree order: order-free logsumexp sums, hardware exp2/log2; NOT bit-comparable "
                      "with the reference (include/rnamc.h, rnamc_ctx_set summation_mode)",
         "roofline": {
-            "kernel": "k_tree_inside2 + k_tree_outside2 (whole sweep, two anti-diagonals per launch)",
+            "kernel": "k_tree_inside2 + k_tree_outside2 (whole sweep, two anti-diagonals per launch) with "
+                      "k_tree_mid / k_tree_ext beside them (banded mid-field, second stream)",
             "bound": "hbm", "achieved": by["b_8d"] / (med * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": by["b_8d"] / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
             "bytes": "SURVEY 8d streamed-operand model of the reference's loops "
@@ -207,8 +213,8 @@ def tree_leg(ctx, torch, dev, stream, seq, contra, reps, f, ref=None):
             "frac": (by["inside"] + by["outside"]) / ((st["ms_inside"] + st["ms_outside"]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
         },
         "roofline_valu": {
-            "what": "f32 VALU issue slots counted from the kernels (8.5 per product term incl. exp2 at "
-                    "2 slots, ~45 per 2-loop probe) against 256 CUs x 4 SIMD-32 x 2.4 GHz",
+            "what": "f32 VALU issue slots counted from the kernels (~10 per product term incl. exp2 at "
+                    "quarter rate, ~45 per 2-loop probe) against 256 CUs x 4 SIMD-32 x 2.4 GHz",
             "bound": "valu", "slots": by["valu_slots"], "peak_slots_per_s": VALU_PEAK_LANE_OPS,
             "time_at_peak_ms": by["valu_slots"] / VALU_PEAK_LANE_OPS * 1e3,
             "frac": by["valu_slots"] / VALU_PEAK_LANE_OPS / (med * 1e-3),

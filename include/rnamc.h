@@ -237,7 +237,10 @@ int rnamc_ctx_set_params(rnamc_ctx* ctx, const rnamc_params* params);
  * "fuse_inside","dual_outside","dual_min_cells","dual_max_diag","order_inside","order_outside",
  * "latency_mode","lat_max_cells","lat_inside","lat_e_waves","lat_pairs",
  * "lat_merge","lat_zr_ahead","profile"; tree-order mode: "tree_two" (two anti-diagonals per
- * launch, default 1), "tree_tpc" (threads per cell: 64 / 256 / 1024, 0 = by diagonal size). */
+ * launch, default 1), "tree_tpc" (threads per cell: 64 / 128 / 256 / 1024, 0 = by diagonal size),
+ * "tree_band" (width of a band of anti-diagonals whose cubic products take their mid-field from
+ * the tiled kernel k_tree_mid one band ahead: 0 / 32 / 64 / 96 / 128, default 64; 0 = every launch
+ * walks its sums whole), "tree_mid_wgs" (workgroups of a mid-field launch, default 256). */
 int rnamc_ctx_set(rnamc_ctx* ctx, const char* name, int64_t value);
 
 /* mccaskill_algo over a batch (src/mccaskill_algo.rs:247-280 for each record, as

@@ -75,7 +75,7 @@ struct rnamc_ctx {
   int64_t tree_two = 1;  // tree mode: two diagonals per launch
   // tree mode: width of a band of diagonals whose products take their mid-field from k_tree_mid
   // (a multiple of 32, at most 128; 0: every launch walks its sums whole)
-  int64_t tree_band = 32;
+  int64_t tree_band = 64;
   hipStream_t bulk_stream = nullptr;  // k_tree_mid, beside the sweep (lowest priority)
   int64_t tree_debug = 0;  // (RNAMC_DEBUG_KNOBS builds: bit 0 no 2-loops, 1 no products, 2 empty kernels)
   int64_t group_max_seqs = 8192;

@@ -1476,8 +1476,9 @@ void launch_tree_static(const TreeBatch& b, bool contra, uint32_t nseq, uint32_t
 void launch_tree_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
                         int64_t tpc_knob, bool two, uint32_t thr, hipStream_t st) {
   const uint32_t cells = max_n - d;
-  // (banded: a cell's product is its edge, at most 2 (d + 1 - thr) terms)
-  const int tpc = tree_tpc(static_cast<uint64_t>(cells) * nseq, thr ? 2u * (d + 1u - thr) : d, tpc_knob);
+  // (banded: the sums are short whatever d is; what more threads per cell buy is one closing-pair
+  // block per wave, so the group is as wide as the chip has room for)
+  const int tpc = tree_tpc(static_cast<uint64_t>(cells) * nseq, thr ? 1024u : d, tpc_knob);
   if (contra) {
     if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_inside2, true, 64);
     else if (tpc == 128) RNAMC_TREE_LAUNCH(k_tree_inside2, true, 128);
@@ -1494,8 +1495,7 @@ void launch_tree_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t ma
 void launch_tree_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
                          int64_t tpc_knob, bool two, uint32_t thr, hipStream_t st) {
   const uint32_t cells = max_n - d;
-  const int tpc = tree_tpc(static_cast<uint64_t>(cells) * nseq, thr ? std::min(max_n - d, thr - d) : max_n - d,
-                           tpc_knob);
+  const int tpc = tree_tpc(static_cast<uint64_t>(cells) * nseq, thr ? 1024u : max_n - d, tpc_knob);
   if (contra) {
     if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_outside2, true, 64);
     else if (tpc == 128) RNAMC_TREE_LAUNCH(k_tree_outside2, true, 128);

@@ -21,13 +21,14 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = colle
 for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         kn = r["Kernel_Name"]
-        k = "k_tree_inside" if "k_tree_inside" in kn else "k_tree_outside" if "k_tree_outside" in kn else "other"
+        k = ("k_tree_inside" if "k_tree_inside" in kn else "k_tree_outside" if "k_tree_outside" in kn
+             else "k_tree_mid" if "k_tree_mid" in kn else "k_tree_ext" if "k_tree_ext" in kn else "other")
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] == "FETCH_SIZE": n[k] += 1
 res = {"workload": "one synthetic sequence n=$N, contra=$CONTRA, tree-order mode, one call per PMC pass",
        "launches": dict(n)}
 tot = 0.0
-for k in ("k_tree_inside", "k_tree_outside"):
+for k in ("k_tree_inside", "k_tree_outside", "k_tree_mid", "k_tree_ext"):
     f, w = agg[k]["FETCH_SIZE"] * 1024, agg[k]["WRITE_SIZE"] * 1024
     # gfx950: FETCH_SIZE tallies 128-B requests at 64 B (MI355X guide, HBM section): doubled
     res[k] = {"fetch_bytes_raw": f, "fetch_bytes_x2": 2 * f, "write_bytes": w, "launches": n[k],

@@ -41,7 +41,7 @@ def run(ctx, seqs, contra, short, mode, **knobs):
     finally:
         ctx.set("summation_mode", 0)
         for k in knobs:
-            ctx.set(k, {"tree_two": 1, "tree_tpc": 0, "tree_band": 32}[k])
+            ctx.set(k, {"tree_two": 1, "tree_tpc": 0, "tree_band": 64}[k])
 
 
 def deviation(a, b):
