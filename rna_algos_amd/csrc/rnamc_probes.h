@@ -329,7 +329,16 @@ __device__ __forceinline__ float probe_fold(const DeviceBatch& b, const Seq& q, 
     float xs[kPU], ps[kPU];
   };
   auto fetch = [&](PBuf& B, uint32_t ra, uint32_t rb) {
+#ifdef RNAMC_PROBE_RESIDENT
+    // timing experiment (results wrong by construction): every probe of the cell re-reads the
+    // cell's first probe, i.e. the 2-loop blocks draw next to nothing from HBM — the upper bound of
+    // what ANY scheme that keeps their operands on chip or compacted could gain
+    ra = 0;
+    rb = 0;
+    const uint32_t blast = 0;
+#else
     const uint32_t blast = lim - ra;  // last probe of the row
+#endif
 #pragma unroll
     for (int u = 0; u < kPU; u++) {
       const uint32_t bb = min(rb + static_cast<uint32_t>(u), blast);

@@ -51,10 +51,9 @@ def run(ctx, seqs, contra, reps=2, label=""):
         print(f"{label} contra={contra} rep{r}: {dt*1e3:.1f} ms  nt/s={lens.sum()/dt:.3e}  "
               f"inside={s['ms_inside']:.1f} outside={s['ms_outside']:.1f} other={s['ms_other']:.1f} ms "
               f"groups={s['n_groups']} T={T:.3e} ns/T={dt*1e9/T:.3f}", flush=True)
-        if s["launches_outside_main"] or s["launches_outside_head"]:
+        if s["launches_outside_main"]:
             print(f"   per kernel: main {s['ms_outside_main']:.1f} ms / {s['launches_outside_main']}, "
                   f"tail {s['ms_outside_tail']:.1f} / {s['launches_outside_tail']}, "
-                  f"head {s['ms_outside_head']:.1f} / {s['launches_outside_head']}, "
                   f"small {s['ms_outside_small']:.1f} / {s['launches_outside_small']}", flush=True)
     return out, logz
 
