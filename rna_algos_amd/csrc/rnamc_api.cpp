@@ -76,6 +76,9 @@ struct rnamc_ctx {
   // tree mode: width of a band of diagonals whose products take their mid-field from k_tree_mid
   // (a multiple of 32, at most 128; 0: every launch walks its sums whole)
   int64_t tree_band = 64;
+  // tree mode, banded sweeps: the far part of a launch's 2-loop blocks is summed by extra
+  // workgroups of the previous launch (rnamc_tree.hip, Ahead)
+  int64_t tree_ahead = 1;
   hipStream_t bulk_stream = nullptr;  // k_tree_mid, beside the sweep (lowest priority)
   int64_t tree_debug = 0;  // (RNAMC_DEBUG_KNOBS builds: bit 0 no 2-loops, 1 no products, 2 empty kernels)
   int64_t group_max_seqs = 8192;
@@ -745,7 +748,8 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
       const uint64_t vec = (static_cast<uint64_t>(n) + 64ull + 63ull) & ~63ull;
       ts.pk_words = static_cast<uint32_t>(((static_cast<uint64_t>(n) + 160) / 16 + 4 + 63) & ~63ull);
       // (mid-field ring: three products x 2 bands of diagonals x vec cells x {max, sum})
-      const uint64_t mid_floats = band ? 3ull * (2ull * band) * vec * 2ull : 0ull;
+      // + the far ring (four diagonals x vec cells x {max, sum})
+      const uint64_t mid_floats = band ? (3ull * (2ull * band) + 4ull) * vec * 2ull : 0ull;
       const uint64_t need = ts.msz * T_COUNT + 2ull * vec + ts.pk_words + mid_floats;
       if (cnt > 0 && (cnt >= static_cast<uint32_t>(c->group_max_seqs) ||
                       cur_nt + n > static_cast<uint64_t>(c->group_max_nt) ||
@@ -871,6 +875,8 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
         launch_tree_ext(b, contra, dlo, dhi, gmax, active(dlo), c->bulk_stream);
         c->stats.launches_other++;
       };
+      const bool ahead = c->tree_ahead != 0 && (c->tree_tpc == 0 || c->tree_tpc == 64);
+      bool use_far = false;  // (the first launch of a sweep forms its blocks whole)
       uint32_t d = dmin_in;
       uint32_t cur_band = ~0u;
       while (d < gmax) {
@@ -890,7 +896,11 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
         }
         const uint32_t thr = x >= 3 ? (x - 1) * band : 0u;
         const bool pair = (d % 2u == 0u) && d + 1 < gmax;
-        launch_tree_inside(b, contra, d, gmax, active(d), c->tree_tpc, pair, thr, st);
+        // the next launch's diagonals: their 2-loop blocks' far parts ride in this launch
+        const uint32_t nd0 = d + (pair ? 2u : 1u);
+        const uint32_t ndc = (!ahead || nd0 >= gmax) ? 0u : ((nd0 % 2u == 0u && nd0 + 1 < gmax) ? 2u : 1u);
+        launch_tree_inside(b, contra, d, gmax, active(d), c->tree_tpc, pair, thr, use_far, nd0, ndc, st);
+        use_far = ndc != 0u;
         c->stats.launches_inside++;
         d += pair ? 2 : 1;
       }
@@ -910,6 +920,7 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
       // the ring and after launch_tree_init.)
       int64_t dd = static_cast<int64_t>(gmax) - 1;
       cur_band = ~0u;
+      use_far = false;
       while (dd >= static_cast<int64_t>(dmin_out)) {
         const uint32_t du = static_cast<uint32_t>(dd);
         const uint32_t x = du / band;
@@ -924,18 +935,26 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
           if ((x + 2) * band < gmax) HIPCHK(hipStreamWaitEvent(st, c->ev_b[x % ering], 0));
         }
         const uint32_t thr = (x + 2) * band < gmax ? (x + 2) * band : 0u;
-        if (du % 2u == 1u && du - 1 >= dmin_out) {
-          launch_tree_outside(b, contra, du - 1, gmax, active(du - 1), c->tree_tpc, true, thr, st);
-          dd -= 2;
-        } else {
-          launch_tree_outside(b, contra, du, gmax, active(du), c->tree_tpc, false, thr, st);
-          dd -= 1;
+        const bool pair = du % 2u == 1u && du - 1 >= dmin_out;
+        const uint32_t lower = pair ? du - 1 : du;
+        // the next launch (below): a pair when its top is odd and both diagonals are swept
+        uint32_t nd0 = 0, ndc = 0;
+        if (ahead && lower >= dmin_out + 1) {
+          const uint32_t top = lower - 1;
+          const bool npair = top % 2u == 1u && top - 1 >= dmin_out;
+          nd0 = npair ? top - 1 : top;
+          ndc = npair ? 2u : 1u;
         }
+        // (sequences that enter the sweep with the next launch need their far parts too)
+        launch_tree_outside(b, contra, lower, gmax, active(ndc ? nd0 : lower), c->tree_tpc, pair, thr, use_far,
+                            nd0, ndc, st);
+        use_far = ndc != 0u;
+        dd -= pair ? 2 : 1;
         c->stats.launches_outside++;
       }
     } else {
     for (uint32_t d = dmin_in; d < gmax; d += two ? 2 : 1) {
-      launch_tree_inside(b, contra, d, gmax, active(d), c->tree_tpc, two, 0u, st);
+      launch_tree_inside(b, contra, d, gmax, active(d), c->tree_tpc, two, 0u, false, 0u, 0u, st);
       c->stats.launches_inside++;
     }
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 1], st));
@@ -946,17 +965,17 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
       int64_t d = static_cast<int64_t>(gmax) - 1;
       for (; d - 1 >= static_cast<int64_t>(dmin_out); d -= 2) {
         launch_tree_outside(b, contra, static_cast<uint32_t>(d - 1), gmax, active(static_cast<uint32_t>(d - 1)),
-                            c->tree_tpc, true, 0u, st);
+                            c->tree_tpc, true, 0u, false, 0u, 0u, st);
         c->stats.launches_outside++;
       }
       if (d >= static_cast<int64_t>(dmin_out)) {
         launch_tree_outside(b, contra, static_cast<uint32_t>(d), gmax, active(static_cast<uint32_t>(d)),
-                            c->tree_tpc, false, 0u, st);
+                            c->tree_tpc, false, 0u, false, 0u, 0u, st);
         c->stats.launches_outside++;
       }
     } else
     for (uint32_t d = gmax; d-- > dmin_out;) {
-      launch_tree_outside(b, contra, d, gmax, active(d), c->tree_tpc, false, 0u, st);
+      launch_tree_outside(b, contra, d, gmax, active(d), c->tree_tpc, false, 0u, false, 0u, 0u, st);
       c->stats.launches_outside++;
     }
     }
@@ -1184,6 +1203,10 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     tree_policy(0, value);
   } else if (k == "tree_mid_wgs" && value >= 1) {
     tree_mid_policy(value);
+  } else if (k == "tree_ahead_waves" && value >= 0) {
+    tree_ahead_policy(value);
+  } else if (k == "tree_ahead") {
+    c->tree_ahead = value;
   } else if (k == "tree_two") {
     c->tree_two = value;
   } else if (k == "tree_band" && value >= 0 && value <= 128 && value % 32 == 0) {

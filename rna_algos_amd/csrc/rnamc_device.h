@@ -96,12 +96,14 @@ enum TreeMat : int {
   T_U = 7,    // column prefix of Zr_mb (first fold of L_c)   col | outside: column prefix of Pm, col
   T_HP = 8,    // hairpin score of the pair (static)                        row
   T_MBC = 9,   // multibranch_close score; -inf = (i,j) may not pair (static) row
-  T_X4 = 10,   // float4 per cell, row (four slots): inside QbX4 = sums_close + IN4,
-               // outside PX4 = (log bpp - sums_close) + CS4
+  T_X4 = 10,   // four planes (one per 2-loop class), row: inside QbX4 = sums_close + IN4[class],
+               // outside PX4 = (log bpp - sums_close) + CS4[class]: a probe reads the plane of its class
   T_ACCS = 14, // accessible score (static)                                  row
   T_CS4 = 15,  // float4 per cell, row: the pair as CLOSING pair of a generic 2-loop, by class (static)
   T_IN4 = 19,  // float4 per cell, row: the pair as ENCLOSED pair (static)
-  T_COUNT = 23
+  T_NEAR4 = 23,  // float4 per cell, row: scores of the pair's three nearest explicit 2-loops,
+                 // enclosed pair (i+1,j-1), (i+1,j-2), (i+2,j-1) (static; .w unused)
+  T_COUNT = 27
 };
 // Length-dependent part of a generic 2-loop score per probe slot (rnamc_tree.hip, probe_slot),
 // derived from rnamc_params on the host (rnamc_api.cpp, build_tree_tabs).  Model index 0 Turner,
@@ -143,15 +145,21 @@ void launch_tree_init(const TreeBatch& b, uint32_t nseq, uint32_t max_n, bool co
 // tpc_knob: threads per cell (64, 256, 1024), anything else = chosen by the diagonal's cells;
 // two: diagonals d and d+1 in one launch (inside: d then d+1; outside: d+1 then d)
 // thr: banded mid-field threshold of the launch's band (0: none; the launch's sums run whole)
+// use_far: the far parts of this launch's 2-loop blocks were written by the previous launch's
+// ahead role; nd0, nd_count: the diagonals of the NEXT launch, whose far parts this launch's extra
+// workgroups write (nd_count = 0: none).  Needs the far ring of a banded workspace (ring != 0).
 void launch_tree_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
-                        int64_t tpc_knob, bool two, uint32_t thr, hipStream_t st);
+                        int64_t tpc_knob, bool two, uint32_t thr, bool use_far, uint32_t nd0,
+                        uint32_t nd_count, hipStream_t st);
 void launch_tree_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
-                         int64_t tpc_knob, bool two, uint32_t thr, hipStream_t st);
+                         int64_t tpc_knob, bool two, uint32_t thr, bool use_far, uint32_t nd0,
+                         uint32_t nd_count, hipStream_t st);
 // Mid-field of the cubic products for the cells of diagonals [dlo, dhi] (one band), threshold thr:
 // inside (outside = false) sums_multibranch, outside probs_multibranch and the Q1 x R part of L_e
 void launch_tree_mid(const TreeBatch& b, bool outside, uint32_t dlo, uint32_t dhi, uint32_t thr,
                      uint32_t max_n, uint32_t nseq, hipStream_t st);
 void tree_mid_policy(int64_t wgs);  // workgroups per k_tree_mid launch
+void tree_ahead_policy(int64_t waves);  // waves up to which the ahead role takes one wave per cell
 // sums_external's first row and last column of a banded sweep, diagonals [dlo, dhi] (in order)
 void launch_tree_ext(const TreeBatch& b, bool contra, uint32_t dlo, uint32_t dhi, uint32_t max_n,
                      uint32_t nseq, hipStream_t st);

@@ -159,11 +159,11 @@ __device__ __forceinline__ Acc wave_reduce(const Acc& a) {
 // after the barrier the first wave reduces the W = TPC / 64 pairs once more; the other waves
 // are done (returns false for them).
 template <int NA, int TPC>
-__device__ __forceinline__ bool cell_reduce(Acc (&a)[NA], float (*lds)[NA][2], int live = NA) {
-  // (`live`, wave-uniform: accumulators [live, NA) are empty in every lane of the group)
+__device__ __forceinline__ bool cell_reduce(Acc (&a)[NA], float (*lds)[NA][2], uint32_t livemask = (1u << NA) - 1u) {
+  // (`livemask`, wave-uniform: bit x clear = accumulator x is empty in every lane of the group)
 #pragma unroll
   for (int x = 0; x < NA; x++)
-    if (x < live) a[x] = wave_reduce(a[x]);
+    if ((livemask >> x) & 1u) a[x] = wave_reduce(a[x]);
   if (TPC == 64) return true;
   constexpr int W = TPC / 64;  // waves per cell group (a 256-thread block holds 256 / TPC groups)
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -171,7 +171,7 @@ __device__ __forceinline__ bool cell_reduce(Acc (&a)[NA], float (*lds)[NA][2], i
   if (lane == 0u) {
 #pragma unroll
     for (int x = 0; x < NA; x++)
-      if (x < live) {
+      if ((livemask >> x) & 1u) {
         lds[wave][x][0] = a[x].m;
         lds[wave][x][1] = a[x].s;
       }
@@ -180,7 +180,7 @@ __device__ __forceinline__ bool cell_reduce(Acc (&a)[NA], float (*lds)[NA][2], i
   if (gw != 0u) return false;
 #pragma unroll
   for (int x = 0; x < NA; x++)
-    if (x < live) {
+    if ((livemask >> x) & 1u) {
       Acc t = lane < static_cast<uint32_t>(W) ? Acc{lds[first + lane][x][0], lds[first + lane][x][1]} : acc_empty();
       a[x] = wave_reduce(t);
     }
@@ -217,6 +217,7 @@ struct TSeq {
   float* out;  // packed diagonal-major triangle: log bpp until k_tree_finalize
   uint32_t batch_idx;
   float2* mid;   // banded mid-field ring: [product][d % ring][i] = {max, sum} (see k_tree_mid)
+  float2* far;   // far parts of the next launch's 2-loop blocks: [d & 3][i] = {max, sum} (see Ahead)
   uint32_t vec;  // cells per ring row
 };
 
@@ -236,6 +237,7 @@ __device__ __forceinline__ TSeq load_tseq(const TreeBatch& b, uint32_t which) {
   q.batch_idx = sd.batch_idx;
   q.mid = reinterpret_cast<float2*>(b.workspace + sd.mid_off);
   q.vec = (sd.n + 64u + 63u) & ~63u;
+  q.far = q.mid + static_cast<size_t>(3u) * b.ring * q.vec;
   return q;
 }
 
@@ -254,6 +256,34 @@ __device__ __forceinline__ uint64_t load_win64(const uint32_t* __restrict__ pk, 
   return (static_cast<uint64_t>(hi) << 32) | lo;
 }
 __device__ __forceinline__ int wb(uint64_t w, uint32_t q) { return static_cast<int>((w >> (2u * q)) & 3u); }
+// the same window at a per-lane position (vector loads)
+__device__ __forceinline__ uint64_t load_win64v(const uint32_t* __restrict__ pk, int p0) {
+  const uint32_t bit = 2u * static_cast<uint32_t>(p0 + 32);
+  const uint32_t w = bit >> 5, sh = bit & 31u;
+  const uint32_t w0 = pk[w], w1 = pk[w + 1], w2 = pk[w + 2];
+  const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
+  const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+  return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+// A 2-loop (i,j) around (k,l) = (i+1+a, j-1-b) reads a pair a + b + 2 diagonals below its own.  With
+// two diagonals per launch the pairs of the last three diagonals are the only ones a launch's
+// blocks cannot have seen one launch earlier: the slots with a + b <= 1, i.e. the first kNear
+// explicit small loops of both models ((0,0) (0,1) (1,0)).  Everything else — the <= 493 FAR
+// slots, all of a block's gathers — is summed by extra workgroups of the PREVIOUS launch
+// (blockIdx.x >= main_blocks; they depend on nothing that launch computes, so they fill the
+// issue slots its chain of round trips leaves idle, and each cell's far part is formed once
+// instead of once per group that needs it) and handed over as a {max, sum} pair.  The outside
+// sweep mirrors it: (k,l) = (i-1-a, j+1+b) lies a + b + 2 diagonals above.
+constexpr uint32_t kNear = 3u;
+#ifndef RNAMC_FAR_NG
+#define RNAMC_FAR_NG 8
+#endif
+constexpr int kFarNG = RNAMC_FAR_NG;  // gathers per lane in flight in the far parts (8 slots per lane)
+struct Ahead {
+  uint32_t flags;        // bit 0: this launch's blocks take their far part from q.far
+  uint32_t main_blocks;  // workgroups of the launch proper; the rest are the ahead role
+  uint32_t nd0, nd_count;  // diagonals of the next launch (nd_count = 0: no ahead role)
+};
 
 // The <= 496 (a, b) pairs with a + b <= 30 (src/mccaskill_algo.rs:306-315) in 512 slots: slot
 // row r < 15 holds the 31 - r pairs of a = r followed by the r + 1 pairs of a = 30 - r; row 15
@@ -427,6 +457,17 @@ __global__ void __launch_bounds__(256) k_tree_static(TreeBatch b) {
       in4 = fixed_side<CONTRA>(b, sj, si, s[j + 1], s[i - 1],
                                CONTRA ? b.params->contra.basepair_scores[si][sj] : 0.f);
     reinterpret_cast<float4*>(q.m[T_IN4])[o] = in4;
+    // the three nearest explicit 2-loops this pair closes (slots (0,0) (0,1) (1,0): kNear), so
+    // that the sweep's launches find their scores with the cell's other operands
+    float nr[3] = {0.f, 0.f, 0.f};
+    for (uint32_t t = 0; t < kNear; t++) {
+      uint32_t a, bb;
+      Special<CONTRA>::slot(t, a, bb);
+      if (a + bb + 3u <= d)
+        nr[t] = TModel<CONTRA>::twoloop(b, a, bb, si, sj, s[i + 1], s[i + 2], s[j - 1], s[j - 2], s[i + 1 + a],
+                                        s[j - 1 - bb], s[j - bb], s[i + a]);
+    }
+    reinterpret_cast<float4*>(q.m[T_NEAR4])[o] = make_float4(nr[0], nr[1], nr[2], 0.f);
   }
 }
 
@@ -443,10 +484,11 @@ __device__ __forceinline__ void pair_block(const TreeBatch& b, const TSeq& q, Ac
   if (b.debug & 1) return;
 #endif
   if (d < 3u) return;
-  const float4* __restrict__ qx4 = reinterpret_cast<const float4*>(q.m[T_X4]);
+  const float* __restrict__ qx = q.m[T_X4];  // four planes, one per class
+  const size_t msz = static_cast<size_t>(q.m[1] - q.m[0]);
   const float* __restrict__ tlen = &b.tabs->len[CONTRA ? 1 : 0][0];
   constexpr int NP = (512 + TPC - 1) / TPC;
-  float4 g[NP];
+  float g[NP];
   float ln[NP];
   uint32_t cls[NP];
   // every gather of the block first (one round trip), then the sums
@@ -457,7 +499,7 @@ __device__ __forceinline__ void pair_block(const TreeBatch& b, const TSeq& q, Ac
     const bool ok = p < 512u && probe_slot(p, a, bb) && !Special<CONTRA>::is(a, bb) && a + bb + 3u <= d;
     cls[u] = slot_class(a, bb);
     ln[u] = ok ? tlen[p] : kNegInf;
-    g[u] = ok ? qx4[static_cast<size_t>(i + 1u + a) * ld + (j - 1u - bb)] : make_float4(0.f, 0.f, 0.f, 0.f);
+    g[u] = ok ? qx[cls[u] * msz + static_cast<size_t>(i + 1u + a) * ld + (j - 1u - bb)] : 0.f;
   }
   float sx = kNegInf;  // the lane's small explicit loop, if it has one
   if (t < Special<CONTRA>::N) {
@@ -477,7 +519,7 @@ __device__ __forceinline__ void pair_block(const TreeBatch& b, const TSeq& q, Ac
   float xv[NP], mx = sx;
 #pragma unroll
   for (int u = 0; u < NP; u++) {
-    xv[u] = (pick(g[u], cls[u]) + ln[u]) + pick(cs4, cls[u]);
+    xv[u] = (g[u] + ln[u]) + pick(cs4, cls[u]);
     mx = vmaxf(mx, xv[u]);
   }
   mx = vmaxf(mx, kEmpty);
@@ -485,6 +527,54 @@ __device__ __forceinline__ void pair_block(const TreeBatch& b, const TSeq& q, Ac
 #pragma unroll
   for (int u = 0; u < NP; u++) sm += ex2((xv[u] - mx) * kL2E);
   acc_merge(acc, Acc{mx, sm});
+}
+
+// The FAR part of the same block alone (ahead role, one wave per cell): no hairpin / multibranch
+// term, explicit small loops from slot kNear on.  Off the launch's critical path, so the gathers
+// go four per lane at a time (two round trips, half the registers: the kernel stays resident
+// eight waves per SIMD deep).
+template <bool CONTRA>
+__device__ __forceinline__ void pair_far(const TreeBatch& b, const TSeq& q, Acc& acc, uint32_t i, uint32_t j,
+                                         uint32_t t, const float4& cs4, uint64_t wi, uint64_t wj) {
+  const uint32_t d = j - i, ld = q.ld;
+  if (d < 3u) return;
+  const float* __restrict__ qx = q.m[T_X4];  // four planes, one per class
+  const size_t msz = static_cast<size_t>(q.m[1] - q.m[0]);
+  const float* __restrict__ tlen = &b.tabs->len[CONTRA ? 1 : 0][0];
+  float sx = kNegInf;
+  if (t >= kNear && t < Special<CONTRA>::N) {
+    uint32_t a, bb;
+    Special<CONTRA>::slot(t, a, bb);
+    if (a + bb + 3u <= d) {
+      const uint32_t k = i + 1u + a, l = j - 1u - bb;
+      const float x = q.m[T_QB][static_cast<size_t>(k) * ld + l];
+      const float sc = TModel<CONTRA>::twoloop(b, a, bb, wb(wi, 0), wb(wj, 31), wb(wi, 1), wb(wi, 2),
+                                               wb(wj, 30), wb(wj, 29), wb(wi, 1u + a), wb(wj, 30u - bb),
+                                               wb(wj, 31u - bb), wb(wi, a));
+      sx = x + sc;
+    }
+  }
+  acc_add(acc, sx);
+#pragma unroll 1
+  for (uint32_t r = 0; r < 8u / kFarNG; r++) {
+    float g[kFarNG];
+    float ln[kFarNG];
+    uint32_t cls[kFarNG];
+#pragma unroll
+    for (int u = 0; u < kFarNG; u++) {
+      const uint32_t p = t + (kFarNG * r + static_cast<uint32_t>(u)) * 64u;
+      uint32_t a = 0, bb = 0;
+      const bool ok = probe_slot(p, a, bb) && !Special<CONTRA>::is(a, bb) && a + bb + 3u <= d;
+      cls[u] = slot_class(a, bb);
+      ln[u] = ok ? tlen[p] : kNegInf;
+      g[u] = ok ? qx[cls[u] * msz + static_cast<size_t>(i + 1u + a) * ld + (j - 1u - bb)] : 0.f;
+    }
+    float xv[kFarNG];
+#pragma unroll
+    for (int u = 0; u < kFarNG; u++) xv[u] = (g[u] + ln[u]) + pick(cs4, cls[u]);
+#pragma unroll
+    for (int u = 0; u < kFarNG; u += 4) acc_add4(acc, xv[u], xv[u + 1], xv[u + 2], xv[u + 3]);
+  }
 }
 
 // enclosing 2-loops of the finished pair (i,j) (574-593 / 681-700): (k,l) = (i-1-a, j+1+b)
@@ -497,10 +587,11 @@ __device__ __forceinline__ void outer_block(const TreeBatch& b, const TSeq& q, A
   if (b.debug & 1) return;
 #endif
   const uint32_t n = q.n, ld = q.ld;
-  const float4* __restrict__ px4 = reinterpret_cast<const float4*>(q.m[T_X4]);
+  const float* __restrict__ px = q.m[T_X4];  // four planes, one per class
+  const size_t msz = static_cast<size_t>(q.m[1] - q.m[0]);
   const float* __restrict__ tlen = &b.tabs->len[CONTRA ? 1 : 0][0];
   constexpr int NP = (512 + TPC - 1) / TPC;
-  float4 g[NP];
+  float g[NP];
   float ln[NP];
   uint32_t cls[NP];
 #pragma unroll
@@ -510,7 +601,7 @@ __device__ __forceinline__ void outer_block(const TreeBatch& b, const TSeq& q, A
     const bool ok = p < 512u && probe_slot(p, a, bb) && !Special<CONTRA>::is(a, bb) && a < i && j + 1u + bb < n;
     cls[u] = slot_class(a, bb);
     ln[u] = ok ? tlen[p] : kNegInf;
-    g[u] = ok ? px4[static_cast<size_t>(i - 1u - a) * ld + (j + 1u + bb)] : make_float4(0.f, 0.f, 0.f, 0.f);
+    g[u] = ok ? px[cls[u] * msz + static_cast<size_t>(i - 1u - a) * ld + (j + 1u + bb)] : 0.f;
   }
   float sx = kNegInf;
   if (t < Special<CONTRA>::N) {
@@ -531,7 +622,7 @@ __device__ __forceinline__ void outer_block(const TreeBatch& b, const TSeq& q, A
   float xv[NP], mx = sx;  // (absent pair: its slot holds -inf)
 #pragma unroll
   for (int u = 0; u < NP; u++) {
-    xv[u] = ((pick(g[u], cls[u]) + qb) + ln[u]) + pick(in4, cls[u]);
+    xv[u] = ((g[u] + qb) + ln[u]) + pick(in4, cls[u]);
     mx = vmaxf(mx, xv[u]);
   }
   mx = vmaxf(mx, kEmpty);
@@ -539,6 +630,52 @@ __device__ __forceinline__ void outer_block(const TreeBatch& b, const TSeq& q, A
 #pragma unroll
   for (int u = 0; u < NP; u++) sm += ex2((xv[u] - mx) * kL2E);
   acc_merge(acc, Acc{mx, sm});
+}
+
+// far part of the same, as pair_far
+template <bool CONTRA>
+__device__ __forceinline__ void outer_far(const TreeBatch& b, const TSeq& q, Acc& acc, uint32_t i, uint32_t j,
+                                          uint32_t t, float qb, const float4& in4, uint64_t wi, uint64_t wj) {
+  const uint32_t n = q.n, ld = q.ld;
+  const float* __restrict__ px = q.m[T_X4];  // four planes, one per class
+  const size_t msz = static_cast<size_t>(q.m[1] - q.m[0]);
+  const float* __restrict__ tlen = &b.tabs->len[CONTRA ? 1 : 0][0];
+  float sx = kNegInf;
+  if (t >= kNear && t < Special<CONTRA>::N) {
+    uint32_t a, bb;
+    Special<CONTRA>::slot(t, a, bb);
+    if (a < i && j + 1u + bb < n) {
+      const uint32_t k = i - 1u - a, l = j + 1u + bb;
+      const float x = q.m[T_QB][static_cast<size_t>(k) * ld + l];
+      const float pkl = q.out[tri_off(n, l - k) + k];
+      const float sc = TModel<CONTRA>::twoloop(b, a, bb, wb(wi, 30u - a), wb(wj, 1u + bb), wb(wi, 31u - a),
+                                               wb(wi, a >= 1u ? 32u - a : 31u), wb(wj, bb),
+                                               wb(wj, bb >= 1u ? bb - 1u : 0u), wb(wi, 31), wb(wj, 0),
+                                               wb(wj, 1), wb(wi, 30));
+      if (x > kNegInf) sx = ((pkl + qb) - x) + sc;
+    }
+  }
+  acc_add(acc, sx);
+#pragma unroll 1
+  for (uint32_t r = 0; r < 8u / kFarNG; r++) {
+    float g[kFarNG];
+    float ln[kFarNG];
+    uint32_t cls[kFarNG];
+#pragma unroll
+    for (int u = 0; u < kFarNG; u++) {
+      const uint32_t p = t + (kFarNG * r + static_cast<uint32_t>(u)) * 64u;
+      uint32_t a = 0, bb = 0;
+      const bool ok = probe_slot(p, a, bb) && !Special<CONTRA>::is(a, bb) && a < i && j + 1u + bb < n;
+      cls[u] = slot_class(a, bb);
+      ln[u] = ok ? tlen[p] : kNegInf;
+      g[u] = ok ? px[cls[u] * msz + static_cast<size_t>(i - 1u - a) * ld + (j + 1u + bb)] : 0.f;
+    }
+    float xv[kFarNG];
+#pragma unroll
+    for (int u = 0; u < kFarNG; u++) xv[u] = ((g[u] + qb) + ln[u]) + pick(in4, cls[u]);
+#pragma unroll
+    for (int u = 0; u < kFarNG; u += 4) acc_add4(acc, xv[u], xv[u + 1], xv[u + 2], xv[u + 3]);
+  }
 }
 
 // ----------------------------------------------------------------------------
@@ -643,6 +780,12 @@ __device__ __forceinline__ void acc_product_2b_lo(Acc& acc0, Acc& acc1, const fl
     acc_add4(acc1, x1[0], x1[1], x1[2], x1[3]);
   }
 }
+// Far parts of the closing-pair blocks (inside) / enclosing 2-loops (outside) of a diagonal's
+// cells, written one launch ahead: ring of four diagonals, {max, sum} per cell
+__device__ __forceinline__ Acc load_far(const TSeq& q, uint32_t d, uint32_t i) {
+  const float2 v = sload2(q.far + static_cast<size_t>(d & 3u) * q.vec + i);
+  return Acc{v.x, v.y};
+}
 __device__ __forceinline__ Acc load_mid(const TSeq& q, uint32_t ring, uint32_t prod, uint32_t d, uint32_t i) {
   const float2 v = sload2(q.mid + (static_cast<size_t>(prod) * ring + d % ring) * q.vec + i);
   return Acc{v.x, v.y};
@@ -651,9 +794,12 @@ __device__ __forceinline__ Acc load_mid(const TSeq& q, uint32_t ring, uint32_t p
 // `thr` (inside): banded cells.  The terms of sums_multibranch(i,j) whose two operands both span
 // less than thr were summed by k_tree_mid before this band started (they need nothing of the
 // last two bands); the launch adds the rest (at most 2 (d - thr) terms: the EDGE) and merges.
-template <bool CONTRA, int TPC>
+// UF: the far parts of this launch's blocks come from q.far (TPC == 64 only; a variant of its own
+// so that neither form carries the other's registers)
+template <bool CONTRA, int TPC, bool UF>
 __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatch b, uint32_t d, int single,
-                                                                        uint32_t thr) {
+                                                                        uint32_t thr, Ahead ah) {
+  static_assert(!UF || TPC == 64, "far parts from the ring: one wave per cell pair");
   constexpr int BLOCK = TPC < 256 ? 256 : TPC;
   constexpr int NA = 9;
   __shared__ float red[BLOCK / 64][NA][2];
@@ -662,10 +808,47 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
 #endif
   const TSeq q = load_tseq(b, blockIdx.y);
   const uint32_t n = q.n, ld = q.ld;
+  if (blockIdx.x >= ah.main_blocks) {
+    // ---- the NEXT launch's closing-pair blocks, far part (see Ahead): one wave per row i takes
+    // the cells (i, i+nd0) and (i, i+nd0+1); nothing here depends on this launch's cells
+#ifdef RNAMC_DEBUG_KNOBS
+    if (b.debug & 1) return;
+#endif
+    // (flags bit 1: one wave per CELL instead of one per row — the launch has room for them)
+    const bool split = (ah.flags & 2u) != 0u;
+    const uint32_t wid = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
+        static_cast<int>((blockIdx.x - ah.main_blocks) * (BLOCK / 64) + threadIdx.x / 64)));
+    const uint32_t i = split ? wid >> 1 : wid;
+    const bool doA = !split || (wid & 1u) == 0u, doB = !split || (wid & 1u) != 0u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const size_t row_i = static_cast<size_t>(i) * ld;
+    const uint64_t wi = load_win64(q.pk, static_cast<int>(i));
+    // (both cells' uniform operands in one round trip; a cell past the row's end reads the pad)
+    const uint32_t j0 = i + ah.nd0;
+    if (j0 >= n) return;
+    const bool two = doB && ah.nd_count > 1u && j0 + 1u < n;
+    const float mbcA = doA ? sload(q.m[T_MBC] + row_i + j0) : kNegInf;
+    const float mbcB = two ? sload(q.m[T_MBC] + row_i + j0 + 1u) : kNegInf;
+    const float4 csA = sload4(reinterpret_cast<const float4*>(q.m[T_CS4]) + row_i + j0);
+    const float4 csB = sload4(reinterpret_cast<const float4*>(q.m[T_CS4]) + row_i + j0 + (two ? 1u : 0u));
+    const uint64_t wjA = load_win64(q.pk, static_cast<int>(j0) - 31);
+    const uint64_t wjB = load_win64(q.pk, static_cast<int>(j0) - 30);
+    Acc fA = acc_empty(), fB = acc_empty();
+    if (mbcA > kNegInf) pair_far<CONTRA>(b, q, fA, i, j0, lane, csA, wi, wjA);
+    if (mbcB > kNegInf) pair_far<CONTRA>(b, q, fB, i, j0 + 1u, lane, csB, wi, wjB);
+    if (mbcA > kNegInf) fA = wave_reduce(fA);
+    if (mbcB > kNegInf) fB = wave_reduce(fB);
+    if (lane == 0u) {
+      if (doA) q.far[static_cast<size_t>(ah.nd0 & 3u) * q.vec + i] = make_float2(fA.m, fA.s);
+      if (two) q.far[static_cast<size_t>((ah.nd0 + 1u) & 3u) * q.vec + i] = make_float2(fB.m, fB.s);
+    }
+    return;
+  }
   // (wave-uniform: TPC is a multiple of 64)
   const uint32_t i = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
       static_cast<int>(blockIdx.x * (BLOCK / TPC) + threadIdx.x / TPC)));
   if (i + d >= n) return;
+  constexpr bool uf = UF;
   const uint32_t j = i + d, j1 = j + 1u;
   const bool has1 = !single && j1 < n;  // cells (i, j+1) and (i+1, j+1) are this launch's too
   const uint32_t t = threadIdx.x % TPC;
@@ -680,7 +863,9 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
   const uint32_t wv = TPC == 64 ? 0u : static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(t >> 6)));
   const bool w0 = wv == 0u;
   // (one wave: all three blocks; two waves: (i,j) and (i,j+1) in the first, the neighbour's in the second)
-  const bool do0 = w0, don = TPC == 64 || wv == 1u, do1 = TPC == 64 || wv == (TPC == 128 ? 0u : 2u);
+  // (far parts taken from q.far: what is left of the three blocks is the first wave's)
+  const bool do0 = w0, don = uf ? w0 : (TPC == 64 || wv == 1u),
+             do1 = uf ? w0 : (TPC == 64 || wv == (TPC == 128 ? 0u : 2u));
   const uint32_t lane = t & 63u;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   // every uniform operand a wave needs, one round trip (scalar unit)
@@ -741,6 +926,37 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
 #pragma unroll
   for (int x = 0; x < NA; x++) acc[x] = acc_empty();
   // [0] [1] [2] closing-pair blocks of (i,j), (i+1,j+1), (i,j+1): one wave each
+  float nx = kNegInf;  // (uf) lane 3c + s: near slot s of cell c
+  Acc far0 = acc_empty(), farn = acc_empty(), far1 = acc_empty();
+  if constexpr (uf) {
+    if (w0) {
+      // Near part: the explicit small loops with a + b <= 1 (inner pairs of the last three
+      // diagonals) — slot s of cell c in lane 3c + s, all nine at once; the far parts were summed
+      // by the previous launch's ahead blocks
+      far0 = load_far(q, d, i);
+      if (has1) {
+        farn = load_far(q, d, i + 1u);  // (the neighbour sits on this diagonal)
+        far1 = load_far(q, d + 1u, i);
+      }
+      const float4* __restrict__ nr4 = reinterpret_cast<const float4*>(q.m[T_NEAR4]);
+      const float4 nr0 = sload4(nr4 + row_i + j);
+      const float4 nrn = has1 ? sload4(nr4 + row_i + ld + j1) : zero4;
+      const float4 nr1 = has1 ? sload4(nr4 + row_i + j1) : zero4;
+      const uint32_t c = lane / 3u, sl = lane - 3u * c;
+      const bool mine = lane < 9u && (c == 0u ? act0 : (c == 1u ? actn : act1));
+      if (mine) {
+        const uint32_t ci = c == 1u ? i + 1u : i, cj = c == 0u ? j : j1;
+        uint32_t a, bb;
+        Special<CONTRA>::slot(sl, a, bb);
+        if (a + bb + 3u <= cj - ci) {
+          const uint32_t k = ci + 1u + a, l = cj - 1u - bb;
+          const float x = q.m[T_QB][static_cast<size_t>(k) * ld + l];
+          const float sc = c == 0u ? pick(nr0, sl) : (c == 1u ? pick(nrn, sl) : pick(nr1, sl));
+          nx = x + sc;
+        }
+      }
+    }
+  } else {
   if (act0 && do0)
     pair_block<CONTRA, 64>(b, q, acc[0], i, j, lane, hp0, qm0 + mbc0, cs0,
                            load_win64(q.pk, static_cast<int>(i)), load_win64(q.pk, static_cast<int>(j) - 31));
@@ -750,6 +966,7 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
   if (act1 && do1)
     pair_block<CONTRA, 64>(b, q, acc[2], i, j1, lane, hp1, qm1 + mbc1, cs1,
                            load_win64(q.pk, static_cast<int>(i)), load_win64(q.pk, static_cast<int>(j) - 30));
+  }
   // [3] [4] sums_multibranch of (i,j) and (i,j+1): k = i+1 .. j-1 | j, Q1(i,k-1) + Zr_mb(k,j | j+1)
   // (the k = i+1 term of the second reads a cell of this launch: left out, it carries Q1(i,i) = -inf)
 #ifdef RNAMC_DEBUG_KNOBS
@@ -795,7 +1012,23 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
     }
   }
   // (the sums_external accumulators [5..8] live only in row 0 and in the column n-1 groups)
-  if (!cell_reduce<NA, TPC>(acc, red, (row0 || zs0 || zs1) ? NA : 5)) return;
+  if (!cell_reduce<NA, TPC>(acc, red, ((row0 || zs0 || zs1) ? 0x1ffu : 0x1fu) & (uf ? ~7u : ~0u))) return;
+  if constexpr (uf) {
+    // the blocks' sums: far part, hairpin, multibranch term, three near slots (uniform values)
+    auto lanev = [&](uint32_t l) {
+      return __uint_as_float(static_cast<uint32_t>(
+          __builtin_amdgcn_readlane(static_cast<int>(__float_as_uint(nx)), static_cast<int>(l))));
+    };
+    acc[0] = far0;
+    acc_add4(acc[0], hp0, qm0 + mbc0, lanev(0), lanev(1));
+    acc_add(acc[0], lanev(2));
+    acc[1] = farn;
+    acc_add4(acc[1], hpn, qmn + mbcn, lanev(3), lanev(4));
+    acc_add(acc[1], lanev(5));
+    acc[2] = far1;
+    acc_add4(acc[2], hp1, qm1 + mbc1, lanev(6), lanev(7));
+    acc_add(acc[2], lanev(8));
+  }
 #ifdef RNAMC_DEBUG_KNOBS
   if (b.debug & 16) {  // timing: no epilogue
     if (t == 0u && acc[0].s + acc[1].s + acc[2].s + acc[3].s + acc[4].s == 12345.f) q.zp[0] = 1.f;
@@ -809,7 +1042,14 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
                              : b.params->turner.coeff_num_branches;
   const float mb_un = CONTRA ? b.params->contra.multibranch_score_unpair : 0.f;
   const bool st = t == 0u;  // the lane that stores
-  float4* __restrict__ qx4 = reinterpret_cast<float4*>(q.m[T_X4]);
+  float* __restrict__ qx = q.m[T_X4];
+  const size_t xsz = static_cast<size_t>(q.m[1] - q.m[0]);
+  auto store_x4 = [&](size_t o, float v, const float4& w) {
+    qx[o] = v + w.x;
+    qx[xsz + o] = v + w.y;
+    qx[2u * xsz + o] = v + w.z;
+    qx[3u * xsz + o] = v + w.w;
+  };
   // ---- cell (i,j)
   float qa0 = kNegInf;
   if (act0) {
@@ -819,7 +1059,7 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
       if (st) {
         q.m[T_QB][row_i + j] = qb;
         q.m[T_QA][row_i + j] = qa0;
-        qx4[row_i + j] = make_float4(qb + in0.x, qb + in0.y, qb + in0.z, qb + in0.w);
+        store_x4(row_i + j, qb, in0);
       }
     }
   }
@@ -870,7 +1110,7 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
       if (st) {
         q.m[T_QB][row_i + j1] = qb;
         q.m[T_QA][row_i + j1] = qa1;
-        qx4[row_i + j1] = make_float4(qb + in1.x, qb + in1.y, qb + in1.z, qb + in1.w);
+        store_x4(row_i + j1, qb, in1);
       }
     }
   }
@@ -947,9 +1187,10 @@ __device__ __forceinline__ void acc_product_3(Acc& pm0, Acc& pmn, Acc& pm1,
 // `thr` (outside): banded cells.  The terms of probs_multibranch and of L_e (cases one / three)
 // whose OUTSIDE operand (W(i,k), R(k,j)) spans at least thr were summed by k_tree_mid before
 // the band above this one started; the launch adds the nearer ones and merges.
-template <bool CONTRA, int TPC>
+template <bool CONTRA, int TPC, bool UF>
 __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBatch b, uint32_t d, int single,
-                                                                         uint32_t thr) {
+                                                                         uint32_t thr, Ahead ah) {
+  static_assert(!UF || TPC == 64, "far parts from the ring: one wave per cell pair");
   constexpr int BLOCK = TPC < 256 ? 256 : TPC;
   constexpr int NA = 7;
   __shared__ float red[BLOCK / 64][NA][2];
@@ -958,9 +1199,44 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBat
 #endif
   const TSeq q = load_tseq(b, blockIdx.y);
   const uint32_t n = q.n, ld = q.ld;
+  if (blockIdx.x >= ah.main_blocks) {
+    // ---- the NEXT launch's enclosing 2-loops, far part (see Ahead): one wave per row i takes
+    // the cells (i, i+nd0) and (i, i+nd0+1)
+#ifdef RNAMC_DEBUG_KNOBS
+    if (b.debug & 1) return;
+#endif
+    const bool split = (ah.flags & 2u) != 0u;
+    const uint32_t wid = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
+        static_cast<int>((blockIdx.x - ah.main_blocks) * (BLOCK / 64) + threadIdx.x / 64)));
+    const uint32_t i = split ? wid >> 1 : wid;
+    const bool doA = !split || (wid & 1u) == 0u, doB = !split || (wid & 1u) != 0u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const size_t row_i = static_cast<size_t>(i) * ld;
+    const uint64_t wi = load_win64(q.pk, static_cast<int>(i) - 31);
+    const uint32_t j0 = i + ah.nd0;
+    if (j0 >= n) return;
+    const bool two = doB && ah.nd_count > 1u && j0 + 1u < n;
+    const float qbA = doA ? sload(q.m[T_QB] + row_i + j0) : kNegInf;
+    const float qbB = two ? sload(q.m[T_QB] + row_i + j0 + 1u) : kNegInf;
+    const float4 inA = sload4(reinterpret_cast<const float4*>(q.m[T_IN4]) + row_i + j0);
+    const float4 inB = sload4(reinterpret_cast<const float4*>(q.m[T_IN4]) + row_i + j0 + (two ? 1u : 0u));
+    const uint64_t wjA = load_win64(q.pk, static_cast<int>(j0));
+    const uint64_t wjB = load_win64(q.pk, static_cast<int>(j0) + 1);
+    Acc fA = acc_empty(), fB = acc_empty();
+    if (qbA > kNegInf) outer_far<CONTRA>(b, q, fA, i, j0, lane, qbA, inA, wi, wjA);
+    if (qbB > kNegInf) outer_far<CONTRA>(b, q, fB, i, j0 + 1u, lane, qbB, inB, wi, wjB);
+    if (qbA > kNegInf) fA = wave_reduce(fA);
+    if (qbB > kNegInf) fB = wave_reduce(fB);
+    if (lane == 0u) {
+      if (doA) q.far[static_cast<size_t>(ah.nd0 & 3u) * q.vec + i] = make_float2(fA.m, fA.s);
+      if (two) q.far[static_cast<size_t>((ah.nd0 + 1u) & 3u) * q.vec + i] = make_float2(fB.m, fB.s);
+    }
+    return;
+  }
   const uint32_t i = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
       static_cast<int>(blockIdx.x * (BLOCK / TPC) + threadIdx.x / TPC)));
   if (i + d >= n) return;
+  constexpr bool uf = UF;
   const uint32_t j = i + d, j1 = j + 1u;
   const bool has1 = !single && j1 < n;
   const uint32_t t = threadIdx.x % TPC;
@@ -977,7 +1253,7 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBat
   // 2-loops each, the first wave alone the scalar operands and the epilogue
   const uint32_t wv = TPC == 64 ? 0u : static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(t >> 6)));
   const bool w0 = wv == 0u;
-  const bool do0 = w0, do1 = TPC == 64 || wv == 1u;
+  const bool do0 = w0, do1 = uf ? w0 : (TPC == 64 || wv == 1u);
   const uint32_t lane = t & 63u;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const float qb0 = sload(qb_r + row_i + j);
@@ -1014,12 +1290,37 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBat
 #pragma unroll
   for (int x = 0; x < NA; x++) acc[x] = acc_empty();
   // [3] [4] enclosing 2-loops of (i,j) and (i,j+1): one wave each
+  float nx = kNegInf;  // (uf) lane 3c + s: near slot s of cell c
+  Acc far0 = acc_empty(), far1 = acc_empty();
+  if constexpr (uf) {
+    if (w0) {
+      // near part (the enclosing pairs of the last three diagonals): slot s of cell c in lane 3c + s
+      far0 = load_far(q, d, i);
+      if (has1) far1 = load_far(q, d + 1u, i);
+      const uint32_t c = lane / 3u, sl = lane - 3u * c;
+      if (lane < 6u && (c == 0u ? paired0 : paired1)) {
+        const uint32_t cj = c == 0u ? j : j1;
+        const float qbc = c == 0u ? qb0 : qb1;
+        uint32_t a, bb;
+        Special<CONTRA>::slot(sl, a, bb);
+        if (a < i && cj + 1u + bb < n) {
+          const uint32_t k = i - 1u - a, l = cj + 1u + bb;
+          const size_t o = static_cast<size_t>(k) * ld + l;
+          const float x = q.m[T_QB][o];
+          const float pkl = q.out[tri_off(n, l - k) + k];
+          const float sc = q.m[T_NEAR4][4u * o + sl];  // (the closing pair's static: slot sl of (k,l))
+          if (x > kNegInf) nx = ((pkl + qbc) - x) + sc;
+        }
+      }
+    }
+  } else {
   if (paired0 && do0)
     outer_block<CONTRA, 64>(b, q, acc[3], i, j, lane, qb0, in0, load_win64(q.pk, static_cast<int>(i) - 31),
                             load_win64(q.pk, static_cast<int>(j)));
   if (paired1 && do1)
     outer_block<CONTRA, 64>(b, q, acc[4], i, j1, lane, qb1, in1, load_win64(q.pk, static_cast<int>(i) - 31),
                             load_win64(q.pk, static_cast<int>(j) + 1));
+  }
   // [0] Pm(i,j), [1] Pm(i-1,j), [2] Pm(i,j+1): k = j+1 .. n-1 (the k = j+1 term of [0] reads
   // W(i,j+1) of this launch next to Q1(j+1,j) = -inf: harmless)
 #ifdef RNAMC_DEBUG_KNOBS
@@ -1063,14 +1364,31 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBat
       acc_merge(acc[6], e1);
     }
   }
-  if (!cell_reduce<NA, TPC>(acc, red)) return;
+  if (!cell_reduce<NA, TPC>(acc, red, uf ? 0x67u : 0x7fu)) return;
+  if constexpr (uf) {
+    auto lanev = [&](uint32_t l) {
+      return __uint_as_float(static_cast<uint32_t>(
+          __builtin_amdgcn_readlane(static_cast<int>(__float_as_uint(nx)), static_cast<int>(l))));
+    };
+    acc[3] = far0;
+    acc_add4(acc[3], lanev(0), lanev(1), lanev(2), kNegInf);
+    acc[4] = far1;
+    acc_add4(acc[4], lanev(3), lanev(4), lanev(5), kNegInf);
+  }
 
   const bool st = t == 0u;
   const float mb_un = CONTRA ? b.params->contra.multibranch_score_unpair : 0.f;
   const float ext_bp = CONTRA ? b.params->contra.external_score_basepair : 0.f;
   const float abr = CONTRA ? b.params->contra.multibranch_score_basepair
                            : b.params->turner.coeff_num_branches;
-  float4* __restrict__ px4 = reinterpret_cast<float4*>(q.m[T_X4]);
+  float* __restrict__ px = q.m[T_X4];
+  const size_t xsz = static_cast<size_t>(q.m[1] - q.m[0]);
+  auto store_x4 = [&](size_t o, float v, const float4& w) {
+    px[o] = v + w.x;
+    px[xsz + o] = v + w.y;
+    px[2u * xsz + o] = v + w.z;
+    px[3u * xsz + o] = v + w.w;
+  };
   // ---- cell (i,j+1)
   float w1 = kNegInf, pm2_1 = kNegInf;
   if (has1) {
@@ -1095,7 +1413,7 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBat
           q.out[tri_off(n, d + 1) + i] = lp;
           q.m[T_ZRE][row_i + j1] = w1;
           const float pq = lp - qb1;
-          px4[row_i + j1] = make_float4(pq + cs1.x, pq + cs1.y, pq + cs1.z, pq + cs1.w);
+          store_x4(row_i + j1, pq, cs1);
         }
       }
     }
@@ -1127,7 +1445,7 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBat
     q.out[tri_off(n, d) + i] = lp;
     q.m[T_ZRE][row_i + j] = (lp + mbc0) - qb0;
     const float pq = lp - qb0;
-    px4[row_i + j] = make_float4(pq + cs0.x, pq + cs0.y, pq + cs0.z, pq + cs0.w);
+    store_x4(row_i + j, pq, cs0);
   }
 }
 
@@ -1439,9 +1757,12 @@ void launch_tree_init(const TreeBatch& b, uint32_t nseq, uint32_t max_n, bool co
   hipLaunchKernelGGL(k_tree_init, dim3(gx, nseq, 1), dim3(256), 0, st, b, contra ? 1 : 0, what);
 }
 
-#define RNAMC_TREE_LAUNCH(K, C, T)                                                              \
-  hipLaunchKernelGGL((K<C, T>), dim3((cells + (T < 256 ? 256 / T : 1) - 1) / (T < 256 ? 256 / T : 1), nseq, 1), \
-                     dim3(T < 256 ? 256 : T), 0, st, b, d, two ? 0 : 1, thr)
+#define RNAMC_TREE_LAUNCH(K, C, T, U)                                                            \
+  do {                                                                                            \
+    const uint32_t gx_ = tree_grid<T>(cells, nd0, nd_count, max_n, nseq, ah);                           \
+    hipLaunchKernelGGL((K<C, T, U>), dim3(gx_, nseq, 1), dim3(T < 256 ? 256 : T), 0, st, b, d,    \
+                       two ? 0 : 1, thr, ah);                                                     \
+  } while (0)
 // Threads per cell by the length of a cell's sums (`terms`) and the number of cells: a cell's
 // lanes walk its sums four steps per stream at a time, so `terms / (4 * threads)` dependent
 // round trips set the launch's duration; more threads per cell while the chip has room for them.
@@ -1449,8 +1770,27 @@ void launch_tree_init(const TreeBatch& b, uint32_t nseq, uint32_t max_n, bool co
 // SIMD, 5120 per chip): a launch whose waves need a second round pays every fixed stage of its
 // dependent chain twice (measured: 8192 waves of 256-thread groups took as long as 4096 would
 // have taken twice).
+// grid of a sweep launch: the workgroups of its own cells, then one wave per row of the next
+// launch's first diagonal (the ahead role)
+static uint64_t g_tree_ahead_waves = 1u << 30;  // (rnamc_ctx_set "tree_ahead_waves")
+template <int T>
+static uint32_t tree_grid(uint32_t cells, uint32_t nd0, uint32_t nd_count, uint32_t max_n, uint32_t nseq_,
+                          Ahead& ah) {
+  constexpr uint32_t per = T < 256 ? 256 / T : 1, block = T < 256 ? 256 : T;
+  ah.main_blocks = (cells + per - 1) / per;
+  ah.nd0 = nd0;
+  ah.nd_count = (nd_count && nd0 < max_n) ? nd_count : 0u;
+  uint32_t rows = ah.nd_count ? max_n - nd0 : 0u;
+  // one ahead wave per cell while the launch's waves still fit the chip at once
+  if (ah.nd_count == 2u && static_cast<uint64_t>(cells + 2u * rows) * nseq_ <= g_tree_ahead_waves) {
+    ah.flags |= 2u;
+    rows *= 2u;
+  }
+  return ah.main_blocks + (rows + block / 64 - 1) / (block / 64);
+}
 static uint64_t g_tree_waves = 5120;  // (rnamc_ctx_set "tree_waves" / "tree_short": tuning)
 static uint32_t g_tree_short = 256;
+void tree_ahead_policy(int64_t waves) { g_tree_ahead_waves = waves > 0 ? static_cast<uint64_t>(waves) : 0u; }
 void tree_policy(int64_t waves, int64_t short_terms) {
   if (waves > 0) g_tree_waves = static_cast<uint64_t>(waves);
   if (short_terms > 0) g_tree_short = static_cast<uint32_t>(short_terms);
@@ -1474,38 +1814,48 @@ void launch_tree_static(const TreeBatch& b, bool contra, uint32_t nseq, uint32_t
 }
 
 void launch_tree_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
-                        int64_t tpc_knob, bool two, uint32_t thr, hipStream_t st) {
+                        int64_t tpc_knob, bool two, uint32_t thr, bool use_far, uint32_t nd0,
+                        uint32_t nd_count, hipStream_t st) {
   const uint32_t cells = max_n - d;
+  Ahead ah{use_far ? 1u : 0u, 0u, 0u, 0u};
   // (banded: the sums are short whatever d is; what more threads per cell buy is one closing-pair
   // block per wave, so the group is as wide as the chip has room for)
   const int tpc = tree_tpc(static_cast<uint64_t>(cells) * nseq, thr ? 1024u : d, tpc_knob);
-  if (contra) {
-    if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_inside2, true, 64);
-    else if (tpc == 128) RNAMC_TREE_LAUNCH(k_tree_inside2, true, 128);
-    else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_inside2, true, 256);
-    else RNAMC_TREE_LAUNCH(k_tree_inside2, true, 1024);
+  if (use_far) {  // (one wave per cell pair: what wider groups bought was a block per wave)
+    if (contra) RNAMC_TREE_LAUNCH(k_tree_inside2, true, 64, true);
+    else RNAMC_TREE_LAUNCH(k_tree_inside2, false, 64, true);
+  } else if (contra) {
+    if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_inside2, true, 64, false);
+    else if (tpc == 128) RNAMC_TREE_LAUNCH(k_tree_inside2, true, 128, false);
+    else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_inside2, true, 256, false);
+    else RNAMC_TREE_LAUNCH(k_tree_inside2, true, 1024, false);
   } else {
-    if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_inside2, false, 64);
-    else if (tpc == 128) RNAMC_TREE_LAUNCH(k_tree_inside2, false, 128);
-    else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_inside2, false, 256);
-    else RNAMC_TREE_LAUNCH(k_tree_inside2, false, 1024);
+    if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_inside2, false, 64, false);
+    else if (tpc == 128) RNAMC_TREE_LAUNCH(k_tree_inside2, false, 128, false);
+    else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_inside2, false, 256, false);
+    else RNAMC_TREE_LAUNCH(k_tree_inside2, false, 1024, false);
   }
 }
 
 void launch_tree_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
-                         int64_t tpc_knob, bool two, uint32_t thr, hipStream_t st) {
+                         int64_t tpc_knob, bool two, uint32_t thr, bool use_far, uint32_t nd0,
+                         uint32_t nd_count, hipStream_t st) {
   const uint32_t cells = max_n - d;
+  Ahead ah{use_far ? 1u : 0u, 0u, 0u, 0u};
   const int tpc = tree_tpc(static_cast<uint64_t>(cells) * nseq, thr ? 1024u : max_n - d, tpc_knob);
-  if (contra) {
-    if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_outside2, true, 64);
-    else if (tpc == 128) RNAMC_TREE_LAUNCH(k_tree_outside2, true, 128);
-    else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_outside2, true, 256);
-    else RNAMC_TREE_LAUNCH(k_tree_outside2, true, 1024);
+  if (use_far) {
+    if (contra) RNAMC_TREE_LAUNCH(k_tree_outside2, true, 64, true);
+    else RNAMC_TREE_LAUNCH(k_tree_outside2, false, 64, true);
+  } else if (contra) {
+    if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_outside2, true, 64, false);
+    else if (tpc == 128) RNAMC_TREE_LAUNCH(k_tree_outside2, true, 128, false);
+    else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_outside2, true, 256, false);
+    else RNAMC_TREE_LAUNCH(k_tree_outside2, true, 1024, false);
   } else {
-    if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_outside2, false, 64);
-    else if (tpc == 128) RNAMC_TREE_LAUNCH(k_tree_outside2, false, 128);
-    else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_outside2, false, 256);
-    else RNAMC_TREE_LAUNCH(k_tree_outside2, false, 1024);
+    if (tpc == 64) RNAMC_TREE_LAUNCH(k_tree_outside2, false, 64, false);
+    else if (tpc == 128) RNAMC_TREE_LAUNCH(k_tree_outside2, false, 128, false);
+    else if (tpc == 256) RNAMC_TREE_LAUNCH(k_tree_outside2, false, 256, false);
+    else RNAMC_TREE_LAUNCH(k_tree_outside2, false, 1024, false);
   }
 #undef RNAMC_TREE_LAUNCH
 }

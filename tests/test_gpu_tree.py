@@ -41,7 +41,7 @@ def run(ctx, seqs, contra, short, mode, **knobs):
     finally:
         ctx.set("summation_mode", 0)
         for k in knobs:
-            ctx.set(k, {"tree_two": 1, "tree_tpc": 0, "tree_band": 64}[k])
+            ctx.set(k, {"tree_two": 1, "tree_tpc": 0, "tree_band": 64, "tree_ahead": 1}[k])
 
 
 def deviation(a, b):
@@ -169,8 +169,9 @@ def test_tree_banded_mid_field(ctx, params, contra, short):
     seqs = [O.splitmix_seq(n, 13 * n + 5) for n in lens]
     base, zbase = run(ctx, seqs, contra, short, 1, tree_band=0)
     tol = lambda n: 2 * (2e-5 + 2e-7 * n)
-    for band in (32, 64):
-        m, z = run(ctx, seqs, contra, short, 1, tree_band=band)
+    for band, ahead in ((32, 1), (64, 1), (64, 0)):
+        # (tree_ahead: the far part of a launch's 2-loop blocks summed by the previous launch)
+        m, z = run(ctx, seqs, contra, short, 1, tree_band=band, tree_ahead=ahead)
         for s, a, b0, za, zb in zip(seqs, m, base, z, zbase):
             same, dp = deviation(a.packed, b0.packed)
             assert same and dp <= tol(len(s)), (band, len(s), dp)
@@ -199,7 +200,9 @@ def test_tree_ragged_batch_and_lone_calls(ctx, params):
         for x, s in enumerate(seqs):
             m1, z1 = run(ctx, [s], contra, short, 1, tree_tpc=256)
             same, dp = deviation(m1[0].packed, mb[x].packed)
-            assert same and dp <= 1e-5, (contra, short, len(s), dp)
+            # (in the group a sequence may be swept banded, with its 2-loop blocks' far parts formed
+            # a launch ahead; alone, a short one is not: the same terms grouped differently)
+            assert same and dp <= 2 * (2e-5 + 2e-7 * len(s)), (contra, short, len(s), dp)
             assert abs(float(z1[0]) - float(zb[x])) <= 1e-6 * max(1.0, abs(float(zb[x])))
 
 
