@@ -151,15 +151,15 @@ def tree_bytes(n, f, contra, band=64):
     # cubic products: the mid-field goes through k_tree_mid's LDS tiles (47 operand rows of 16 k
     # staged per 256 cells x 16 k: 0.73 B per term); the launches walk the edge, on average
     # 3 band widths of terms per product and cell pair (3 loads per 2 terms inside and for L_e,
-    # 4 streams per cell pair for probs_multibranch incl. the neighbour's); one 16-byte gather per
-    # generic 2-loop (the neighbour's block is evaluated twice inside); dense stores; the two
-    # sums_external vectors walk n^2 / 2 terms each (k_tree_ext)
+    # 4 streams per cell pair for probs_multibranch incl. the neighbour's); one 4-byte gather per
+    # generic 2-loop (the plane of its class; every cell's far part is formed once, a launch
+    # ahead); dense stores; the two sums_external vectors walk n^2 / 2 terms each (k_tree_ext)
     staged = 47.0 * 16 * 4 / (256 * 16)
     edge = 3.0 * band * n2h / 2.0  # terms walked per product by the launches (per cell PAIR: n2h / 2 pairs)
-    inside = staged * T + 12.0 * edge + 16.0 * 496.0 * f * n2h * 1.5 + 12 * 4.0 * n2h + 2 * 4.0 * n2h
-    outside = staged * T * (1.0 + either) + (16.0 + 12.0 * either) * edge + 16.0 * 496.0 * f * n2h + 10 * 4.0 * n2h
+    inside = staged * T + 12.0 * edge + 4.0 * 496.0 * f * n2h + 15 * 4.0 * n2h + 2 * 4.0 * n2h
+    outside = staged * T * (1.0 + either) + (16.0 + 12.0 * either) * edge + 4.0 * 496.0 * f * n2h + 13 * 4.0 * n2h
     # issue slots: ~10 per product term (add, max, fma, exp2 at quarter rate ...), ~45 per 2-loop probe
-    valu = 10.0 * T * (1.0 + 1.0 + either) + 45.0 * 496.0 * f * n2h * 2.5
+    valu = 10.0 * T * (1.0 + 1.0 + either) + 45.0 * 496.0 * f * n2h * 2.0
     return {"b_8d": b_8d, "inside": inside, "outside": outside, "valu_slots": valu}
 
 
