@@ -864,6 +864,9 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
       };
       auto enqueue_mid = [&](bool outside, uint32_t x, uint32_t thr) -> int {
         const uint32_t dlo = x * band, dhi = std::min(gmax - 1, dlo + band - 1);
+#ifdef RNAMC_DEBUG_KNOBS
+        if (!(c->tree_debug & 32))  // (timing: the sweep without its mid-field kernels; results wrong)
+#endif
         launch_tree_mid(b, outside, dlo, dhi, thr, gmax, active(dlo), c->bulk_stream);
         HIPCHK(hipEventRecord(c->ev_b[x % ering], c->bulk_stream));
         c->stats.launches_other++;
@@ -872,6 +875,9 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
       auto enqueue_ext = [&](uint32_t x) {  // band x of the inside sweep is enqueued whole
         const uint32_t dlo = std::max(dmin_in, x * band), dhi = std::min(gmax - 1, x * band + band - 1);
         if (dlo > dhi) return;
+#ifdef RNAMC_DEBUG_KNOBS
+        if (!(c->tree_debug & 64))
+#endif
         launch_tree_ext(b, contra, dlo, dhi, gmax, active(dlo), c->bulk_stream);
         c->stats.launches_other++;
       };

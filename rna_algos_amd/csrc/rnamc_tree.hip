@@ -815,6 +815,7 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
     if (b.debug & 1) return;
 #endif
     // (flags bit 1: one wave per CELL instead of one per row — the launch has room for them)
+    __builtin_amdgcn_s_setprio(1);
     const bool split = (ah.flags & 2u) != 0u;
     const uint32_t wid = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
         static_cast<int>((blockIdx.x - ah.main_blocks) * (BLOCK / 64) + threadIdx.x / 64)));
@@ -848,6 +849,9 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
   const uint32_t i = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
       static_cast<int>(blockIdx.x * (BLOCK / TPC) + threadIdx.x / TPC)));
   if (i + d >= n) return;
+  // the launch's chain goes first at the issue ports: the mid-field kernel beside it (priority 0)
+  // and the ahead waves (1) take what it leaves
+  __builtin_amdgcn_s_setprio(3);
   constexpr bool uf = UF;
   const uint32_t j = i + d, j1 = j + 1u;
   const bool has1 = !single && j1 < n;  // cells (i, j+1) and (i+1, j+1) are this launch's too
@@ -1205,6 +1209,7 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBat
 #ifdef RNAMC_DEBUG_KNOBS
     if (b.debug & 1) return;
 #endif
+    __builtin_amdgcn_s_setprio(1);
     const bool split = (ah.flags & 2u) != 0u;
     const uint32_t wid = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
         static_cast<int>((blockIdx.x - ah.main_blocks) * (BLOCK / 64) + threadIdx.x / 64)));
@@ -1236,6 +1241,7 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBat
   const uint32_t i = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
       static_cast<int>(blockIdx.x * (BLOCK / TPC) + threadIdx.x / TPC)));
   if (i + d >= n) return;
+  __builtin_amdgcn_s_setprio(3);  // (as in the inside kernel)
   constexpr bool uf = UF;
   const uint32_t j = i + d, j1 = j + 1u;
   const bool has1 = !single && j1 < n;
