@@ -24,6 +24,26 @@ __global__ void k(float* out, int iters, float seed) {
         if (OP == 7) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(*(double*)&a[x & 6]) : "v"(*(double*)&a[(x+2)&6]));
         if (OP == 8) asm volatile("v_lshrrev_b64 %0, 2, %0" : "+v"(*(unsigned long long*)&a[x & 6]));
         if (OP == 9) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[x]) : "v"(c));
+        if (OP == 10) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[x]) : "v"(c));
+        if (OP == 11) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(a[x]));
+        if (OP == 12) asm volatile("v_lshl_add_u32 %0, %0, 4, %1" : "+v"(a[x]) : "v"(c));
+        if (OP == 13) asm volatile("v_and_or_b32 %0, %0, %1, %1" : "+v"(a[x]) : "v"(c));
+        if (OP == 14) asm volatile("v_mul_f32_e64 %0, |%0|, %1" : "+v"(a[x]) : "v"(c));
+        if (OP == 15) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[x]) : "v"(c));
+        if (OP == 16) asm volatile("v_med3_u32 %0, %0, %1, %1" : "+v"(a[x]) : "v"(c));
+        if (OP == 17) asm volatile("v_bfe_u32 %0, %0, 3, 11" : "+v"(a[x]));
+        if (OP == 18) asm volatile("v_cmp_ge_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[x]) : "v"(c) : "vcc");
+        if (OP == 19) asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(*(unsigned long long*)&a[x & 6]) : "v"(*(unsigned long long*)&a[(x + 2) & 6]));
+        if (OP == 20) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[x]) : "v"(c));
+        if (OP == 21) asm volatile("v_bfi_b32 %0, %1, %0, %1" : "+v"(a[x]) : "v"(c));
+        if (OP == 22) asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(a[x]));
+        if (OP == 23) asm volatile("v_sub_f32_e64 %0, %1, |%0|" : "+v"(a[x]) : "v"(c));
+        if (OP == 24) asm volatile("v_max_u32 %0, %0, %1" : "+v"(a[x]) : "v"(c));
+        if (OP == 25) asm volatile("v_cmp_ge_f32 vcc, %0, %1\n v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a[x]) : "v"(c) : "vcc");
+        if (OP == 26) asm volatile("v_add_f32 %0, %0, %1\n v_cmp_ge_f32 vcc, %0, %1\n v_add_f32 %0, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[x]) : "v"(c) : "vcc");
+        if (OP == 27) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[x]) : "v"(c));
+        if (OP == 28) asm volatile("v_cndmask_b32_sdwa %0, %0, %1, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "+v"(a[x]) : "v"(c));
+        if (OP == 29) asm volatile("v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_max_f32 %0, %0, %1" : "+v"(a[x]) : "v"(c));
       }
     }
   }
@@ -71,5 +91,25 @@ int main() {
   run<7>("v_pk_add_f32", 1);
   run<8>("v_lshrrev_b64", 1);
   run<9>("v_and_b32", 1);
+  run<10>("v_sub_f32", 1);
+  run<11>("v_lshrrev_b32", 1);
+  run<12>("v_lshl_add_u32", 1);
+  run<13>("v_and_or_b32", 1);
+  run<14>("v_mul_f32_e64 |abs|", 1);
+  run<15>("v_min_f32", 1);
+  run<16>("v_med3_u32", 1);
+  run<17>("v_bfe_u32", 1);
+  run<18>("v_cmp vcc + v_cndmask vcc", 2);
+  run<19>("v_lshl_add_u64", 1);
+  run<20>("v_add_u32", 1);
+  run<21>("v_bfi_b32", 1);
+  run<22>("v_ashrrev_i32", 1);
+  run<23>("v_sub_f32_e64 |abs|", 1);
+  run<24>("v_max_u32", 1);
+  run<25>("v_cmp vcc + v_addc_co vcc", 2);
+  run<26>("add, cmp vcc, add, cndmask vcc", 4);
+  run<27>("v_xor_b32", 1);
+  run<28>("v_cndmask_b32_sdwa", 1);
+  run<29>("3 x v_add_f32 + v_max_f32", 4);
   return 0;
 }
