@@ -358,6 +358,9 @@ def main():
                          "n=4096, CPU baseline) are dropped, with a note in the line, when the "
                          "W + K passes would not leave room for them")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--share-devices", action="store_true",
+                    help="rehearsal only: rank r uses device r mod device_count, so that N ranks "
+                         "can be rehearsed on fewer GPUs (gloo backend; the line says so)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no device work: exercises launcher, sharding, barrier and the "
                          "max-over-ranks reduction (CPU test of the N > 1 path, with gloo)")
@@ -455,6 +458,13 @@ def main():
 
     from rna_algos_amd.utils import FoldScoreSets
     from rna_algos_amd.mccaskill_algo import Context
+    if args.share_devices:
+        if args.backend != "gloo":
+            print("bench.py: --share-devices needs --backend gloo (RCCL refuses two ranks on one "
+                  "device)", file=sys.stderr)
+            sys.exit(2)
+        local_rank = local_rank % torch.cuda.device_count()
+        label += f" [REHEARSAL: {world} ranks share {torch.cuda.device_count()} device(s)]"
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     params = FoldScoreSets.synthetic(args.param_seed)
