@@ -1132,6 +1132,16 @@ int rnamc_ctx_create(const rnamc_params* params, int device, uint64_t workspace_
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     if (hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, hi) != hipSuccess)
       return fail(RNAMC_ERR_HIP);
+#ifndef RNAMC_DBG_LAZY_BULK
+    // the tree-order mode's side stream (mid-field products, lowest priority) is created HERE,
+    // with the context, not at the first tree-order call: created as the process's fifth or later
+    // stream (after the host entry's copy stream) it no longer gets a hardware queue of its own on
+    // this runtime and its 100-600 us kernels sit in the queue of the sweep's 11 us launches
+    // (measured: the n = 4096 tree-order sweep took 157 ms instead of 49.5 ms at the end of
+    // bench.py's batch run)
+    if (hipStreamCreateWithPriority(&c->bulk_stream, hipStreamNonBlocking, lo) != hipSuccess)
+      return fail(RNAMC_ERR_HIP);
+#endif
   }
   for (int x = 0; x < 16; x++) {
     hipEvent_t ea = nullptr, eb = nullptr;
@@ -1472,6 +1482,25 @@ int rnamc_bpp_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* bases, const u
       c->st_out[k] = nullptr;
       c->st_out_cap[k] = 0;
     }
+#ifdef RNAMC_DBG_VA  // experiment: the copy stream does not outlive the call
+  (void)hipStreamDestroy(c->copy_stream);
+  c->copy_stream = nullptr;
+#endif
+#ifdef RNAMC_DBG_VB  // experiment: nor do the pinned bounce chunks
+  for (int k = 0; k < 2; k++) {
+    (void)hipHostFree(c->pinned[k]);
+    c->pinned[k] = nullptr;
+  }
+#endif
+#ifdef RNAMC_DBG_VD  // experiment: nor do the staging buffers
+  for (int k = 0; k < 2; k++) {
+    (void)hipFree(c->st_out[k]);
+    c->st_out[k] = nullptr;
+    c->st_out_cap[k] = 0;
+  }
+  (void)hipFree(c->st_bases); c->st_bases = nullptr; c->st_bases_cap = 0;
+  (void)hipFree(c->st_logz); c->st_logz = nullptr; c->st_logz_cap = 0;
+#endif
   return RNAMC_OK;
 }
 

@@ -233,3 +233,41 @@ def test_mode_knob_and_fold_scores_unaffected(ctx, params, trnas):
         ctx.set("summation_mode", 0)
     rhp, rmb, rac, rtl = O.fold_scores(params.ptr, s, False, False)
     assert np.array_equal(np.isnan(mb), np.isnan(rmb)) and np.array_equal(tl, rtl)
+
+
+def test_tree_sweep_time_survives_host_entry(params):
+    """The banded sweep's side stream (mid-field products) must own a hardware queue: created as a
+    late stream of the process — after the host entry had made its copy stream — it shared the
+    queue of the sweep's 11-us launches and the n = 4096 sweep took 157 ms instead of 49.5 ms
+    (profiles/r03_tree_side_stream_order.txt).  The context now creates it at rnamc_ctx_create;
+    here: a context whose FIRST tree-order call comes after a host-entry batch is no slower than
+    one that starts with it (3.2x before the fix)."""
+    import time
+    from rna_algos_amd.mccaskill_algo import Context
+    rng = np.random.default_rng(31)
+    batch = [rng.integers(0, 4, int(n)).astype(np.uint8) for n in rng.integers(300, 600, 300)]
+    s = O.splitmix_seq(2048, 2048)
+
+    def tree_ms(c):
+        c.set("summation_mode", 1)
+        try:
+            c.bpp_batch([s], False, False)  # allocates the workspace
+            ms = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                c.bpp_batch([s], False, False)
+                ms.append((time.perf_counter() - t0) * 1e3)
+        finally:
+            c.set("summation_mode", 0)
+        return float(np.median(ms))
+
+    a = Context(params, device=0)
+    a.bpp_batch(batch, False, False)  # host entry first: H2D, two-kernel sweeps, drain thread, D2H
+    after = tree_ms(a)
+    a.close()
+    b = Context(params, device=0)
+    fresh = tree_ms(b)
+    b.close()
+    print(f"tree-order n=2048 through the host entry: {after:.1f} ms after a host-entry batch, "
+          f"{fresh:.1f} ms in a fresh context")
+    assert after < 1.6 * fresh
