@@ -1482,25 +1482,6 @@ int rnamc_bpp_batch(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* bases, const u
       c->st_out[k] = nullptr;
       c->st_out_cap[k] = 0;
     }
-#ifdef RNAMC_DBG_VA  // experiment: the copy stream does not outlive the call
-  (void)hipStreamDestroy(c->copy_stream);
-  c->copy_stream = nullptr;
-#endif
-#ifdef RNAMC_DBG_VB  // experiment: nor do the pinned bounce chunks
-  for (int k = 0; k < 2; k++) {
-    (void)hipHostFree(c->pinned[k]);
-    c->pinned[k] = nullptr;
-  }
-#endif
-#ifdef RNAMC_DBG_VD  // experiment: nor do the staging buffers
-  for (int k = 0; k < 2; k++) {
-    (void)hipFree(c->st_out[k]);
-    c->st_out[k] = nullptr;
-    c->st_out_cap[k] = 0;
-  }
-  (void)hipFree(c->st_bases); c->st_bases = nullptr; c->st_bases_cap = 0;
-  (void)hipFree(c->st_logz); c->st_logz = nullptr; c->st_logz_cap = 0;
-#endif
   return RNAMC_OK;
 }
 
