@@ -487,6 +487,11 @@ def main():
     d_logz = torch.empty(len(my_seqs), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
+    def progress(msg):
+        # stderr only (stdout carries the ONE JSON line): a run of many minutes is not silent
+        if rank == 0:
+            print(f"bench.py [{time.time() - T_START:6.1f} s] {msg}", file=sys.stderr, flush=True)
+
     def step():
         ctx.bpp_batch_device(len(my_seqs), d_bases.data_ptr(), offsets, contra, False,
                              d_out.data_ptr(), out_offsets, d_logz.data_ptr(), stream)
@@ -546,6 +551,7 @@ def main():
                                       "host buffers out): H2D + kernels + D2H"}
             pass_s = dt if pass_s is None else min(pass_s, dt)
             del h_out
+            progress(f"warm-up pass {w} of {args.warmup} (host-buffer entry): {dt:.2f} s")
             continue
         if last and rank == 0 and not args.no_kernel_timing:
             # per-kernel durations for the roofline: a pair of HIP events around every
@@ -557,6 +563,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         pass_s = dt if pass_s is None else min(pass_s, dt)
+        progress(f"warm-up pass {w} of {args.warmup}: {dt:.2f} s")
         if last and rank == 0 and not args.no_kernel_timing:
             st = ctx.stats()
             ctx.set("profile", 1)
@@ -584,6 +591,7 @@ def main():
         step()
         st = ctx.stats()  # event-timed sweeps of this step (the call synchronised its stream)
         step_s.append(time.perf_counter() - ts)
+        progress(f"timed step {len(step_s)} of {steps}: {step_s[-1]:.2f} s")
         ms_in += st["ms_inside"]
         ms_out += st["ms_outside"]
         l_in += st["launches_inside"]
