@@ -62,6 +62,7 @@ extern "C" {
   fn rnamc_bpp_len(n: u32) -> u64;
   fn rnamc_bpp_batch_multi(pool: *mut RnamcPool, n_seqs: u32, bases: *const u8, offsets: *const u64, uses_contra_model: c_int, allows_short_hairpins: c_int, bpp: *mut f32, out_offsets: *const u64, log_partition: *mut f32) -> c_int;
   fn rnamc_fold_scores(ctx: *mut RnamcCtx, bases: *const u8, n: u32, uses_contra_model: c_int, allows_short_hairpins: c_int, hairpin_scores: *mut f32, multibranch_close_scores: *mut f32, accessible_scores: *mut f32, twoloop_scores: *mut TwoloopScore, twoloop_cap: u64, twoloop_count: *mut u64) -> c_int;
+  fn rnamc_fold_sums(ctx: *mut RnamcCtx, bases: *const u8, n: u32, uses_contra_model: c_int, allows_short_hairpins: c_int, sums_external: *mut f32, sums_rightmost_basepairs_external: *mut f32, sums_rightmost_basepairs_multibranch: *mut f32, sums_close: *mut f32, sums_accessible: *mut f32, sums_multibranch: *mut f32, sums_1ormore_basepairs: *mut f32) -> c_int;
 }
 
 // panic with librnamc's own words (the reference panics on the same inputs:
@@ -397,4 +398,51 @@ fn get_fold_scores<T: HashIndex>(
     out.twoloop_scores.insert(key, e.score);
   }
   out
+}
+
+// `FoldSums<T>` of the reference's first stage (src/mccaskill_algo.rs:282-378 / 380-516) from the
+// device: the inside sweep alone through rnamc_fold_sums.  A maintainer who wants the GPU behind
+// `get_fold_sums{,_contra}` as well calls this from their bodies (and `get_fold_scores` above for
+// the `&mut FoldScores<T>` they fill on the way); the crate's own callers never use the stages
+// separately (src/mccaskill_algo.rs:256-279 is the only call site).
+pub fn fold_sums_device<T: HashIndex>(
+  seq: SeqSlice,
+  uses_contra_model: bool,
+  allows_short_hairpins: bool,
+  fold_score_sets: &FoldScoreSets,
+) -> FoldSums<T> {
+  let n = seq.len();
+  let bases: Vec<u8> = seq.iter().map(|&x| x as u8).collect();
+  let mut m: Vec<Vec<f32>> = (0..7).map(|_| vec![0f32; n * n]).collect();
+  with_context(fold_score_sets, |ctx| {
+    let p: Vec<*mut f32> = m.iter_mut().map(|v| v.as_mut_ptr()).collect();
+    check(
+      unsafe {
+        rnamc_fold_sums(ctx, bases.as_ptr(), n as u32, uses_contra_model as c_int,
+          allows_short_hairpins as c_int, p[0], p[1], p[2], p[3], p[4], p[5], p[6])
+      },
+      "rnamc_fold_sums",
+    );
+  });
+  let rows = |v: &Vec<f32>| -> SumMat { v.chunks(n).map(|r| r.to_vec()).collect() };
+  let sparse = |v: &Vec<f32>| -> SparseSumMat<T> {
+    let mut out = SparseSumMat::<T>::default();
+    for i in 0..n {
+      for j in i..n {
+        let x = v[i * n + j];
+        // the reference inserts finite sums only (src/mccaskill_algo.rs:332-338 / 456-462)
+        if x.is_finite() { out.insert((T::from_usize(i).unwrap(), T::from_usize(j).unwrap()), x); }
+      }
+    }
+    out
+  };
+  FoldSums {
+    sums_external: rows(&m[0]),
+    sums_rightmost_basepairs_external: rows(&m[1]),
+    sums_rightmost_basepairs_multibranch: rows(&m[2]),
+    sums_close: sparse(&m[3]),
+    sums_accessible: sparse(&m[4]),
+    sums_multibranch: rows(&m[5]),
+    sums_1ormore_basepairs: rows(&m[6]),
+  }
 }

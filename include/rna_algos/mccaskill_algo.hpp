@@ -163,6 +163,44 @@ FoldScores<T> fold_scores(const Context& ctx, const Seq& seq, bool uses_contra_m
   return out;
 }
 
+// FoldSums<T>, src/mccaskill_algo.rs:3-11: the value of the reference's first stage
+// (get_fold_sums / get_fold_sums_contra, 282 / 380), through rnamc_fold_sums (inside sweep alone)
+using SumMat = std::vector<std::vector<Score>>;
+template <class T>
+struct FoldSums {
+  SumMat sums_external;
+  SumMat sums_rightmost_basepairs_external;
+  SumMat sums_rightmost_basepairs_multibranch;
+  SparseScoreMat<T> sums_close;
+  SparseScoreMat<T> sums_accessible;
+  SumMat sums_multibranch;
+  SumMat sums_1ormore_basepairs;
+};
+template <class T>
+FoldSums<T> get_fold_sums(const Context& ctx, const Seq& seq, bool uses_contra_model,
+                          bool allows_short_hairpins) {
+  const uint32_t n = static_cast<uint32_t>(seq.size());
+  std::vector<std::vector<float>> m(7, std::vector<float>(static_cast<size_t>(n) * n + 1));
+  check(rnamc_fold_sums(ctx.get(), seq.data(), n, uses_contra_model, allows_short_hairpins,
+                        m[0].data(), m[1].data(), m[2].data(), m[3].data(), m[4].data(), m[5].data(),
+                        m[6].data()));
+  auto rows = [n](const std::vector<float>& v) {
+    SumMat out(n);
+    for (uint32_t i = 0; i < n; i++) out[i].assign(v.begin() + static_cast<size_t>(i) * n, v.begin() + static_cast<size_t>(i + 1) * n);
+    return out;
+  };
+  auto sparse = [n](const std::vector<float>& v) {
+    SparseScoreMat<T> out;  // finite sums only, as the reference inserts them (332-338 / 456-462)
+    for (uint32_t i = 0; i < n; i++)
+      for (uint32_t j = i; j < n; j++) {
+        const float x = v[static_cast<size_t>(i) * n + j];
+        if (x - x == 0.f) out.emplace(PosPair<T>(static_cast<T>(i), static_cast<T>(j)), x);
+      }
+    return out;
+  };
+  return {rows(m[0]), rows(m[1]), rows(m[2]), sparse(m[3]), sparse(m[4]), rows(m[5]), rows(m[6])};
+}
+
 // mccaskill_algo, src/mccaskill_algo.rs:247-280
 template <class T>
 std::pair<SparseProbMat<T>, FoldScores<T>> mccaskill_algo(const Context& ctx, const Seq& seq,

@@ -363,6 +363,24 @@ int rnamc_fold_scores(rnamc_ctx* ctx, const uint8_t* bases, uint32_t n, int uses
                       rnamc_twoloop_score* twoloop_scores, uint64_t twoloop_cap,
                       uint64_t* twoloop_count);
 
+/* FoldSums<T> (src/mccaskill_algo.rs:3-11, 213-226): what the reference's first stage,
+ * `pub fn get_fold_sums` / `get_fold_sums_contra` (src/mccaskill_algo.rs:282-378 / 380-516),
+ * returns.  The inside sweep of ONE sequence on the device, always in reference order, then the
+ * seven members as n x n row-major matrices like the reference's Vec<Vec<f32>> (any pointer may
+ * be NULL).  Cells the reference never writes hold its initial values: sums_external 0 (lower
+ * triangle and spans it skips included), the other dense matrices -inf; the two sparse maps
+ * (sums_close, sums_accessible) come dense with -inf for an absent key (the reference inserts
+ * finite values only, src/mccaskill_algo.rs:332-338 / 456-462).  Under Turner the reference never
+ * writes sums_rightmost_basepairs_multibranch: all -inf.  The second stage (`get_basepair_probs*`)
+ * is not offered alone: it reads the caller's FoldScores maps instead of the sequence; the whole
+ * path is rnamc_bpp_batch. */
+int rnamc_fold_sums(rnamc_ctx* ctx, const uint8_t* bases, uint32_t n, int uses_contra_model,
+                    int allows_short_hairpins, float* sums_external,
+                    float* sums_rightmost_basepairs_external,
+                    float* sums_rightmost_basepairs_multibranch, float* sums_close,
+                    float* sums_accessible, float* sums_multibranch,
+                    float* sums_1ormore_basepairs);
+
 /* ------------------------------------------------------------------------- */
 /* Consumers of the path's output, host side. */
 

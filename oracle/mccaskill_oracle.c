@@ -430,6 +430,38 @@ int rnamc_oracle_bpp_dump(const rnamc_params* p, const uint8_t* seq, uint32_t n,
   return RNAMC_OK;
 }
 
+/* get_fold_sums / get_fold_sums_contra alone — mccaskill_algo.rs:282-378 / 380-516: the seven
+ * members of FoldSums<T> (3-11) as the first stage returns them, each n*n row-major
+ * (caller-allocated, entries may be NULL), in the struct's order: sums_external,
+ * sums_rightmost_basepairs_external, sums_rightmost_basepairs_multibranch, sums_close,
+ * sums_accessible, sums_multibranch, sums_1ormore_basepairs.  The sparse maps are dense here with
+ * -inf for an absent key (value-preserving: SURVEY 8a N3). */
+int rnamc_oracle_fold_sums(const rnamc_params* p, const uint8_t* seq, uint32_t n,
+                           int uses_contra_model, int allows_short_hairpins, float** mats) {
+  int st = check_args(p, seq, n);
+  if (st) return st;
+  if (!mats) return RNAMC_ERR_INVALID_ARG;
+  ostate s;
+  st = ostate_init(&s, n);
+  if (st) return st;
+  if (uses_contra_model)
+    o_get_fold_sums_contra(p, seq, &s, allows_short_hairpins);
+  else
+    o_get_fold_sums(p, seq, &s);
+  const Score* src[7] = {s.sums_external,
+                         s.sums_rightmost_basepairs_external,
+                         s.sums_rightmost_basepairs_multibranch,
+                         s.sums_close,
+                         s.sums_accessible,
+                         s.sums_multibranch,
+                         s.sums_1ormore_basepairs};
+  for (int m = 0; m < 7; m++)
+    if (mats[m])
+      for (size_t x = 0; x < (size_t)n * n; x++) mats[m][x] = (float)src[m][x];
+  ostate_free(&s);
+  return RNAMC_OK;
+}
+
 int rnamc_oracle_bpp(const rnamc_params* p, const uint8_t* seq, uint32_t n, int uses_contra_model,
                      int allows_short_hairpins, float* bpp_packed, float* log_partition) {
   return rnamc_oracle_bpp_dump(p, seq, n, uses_contra_model, allows_short_hairpins, bpp_packed,

@@ -24,7 +24,8 @@ SYMBOLS = [
     "rnamc_params_set_special_hairpins", "rnamc_params_set_hairpin_limits",
     "rnamc_ctx_create", "rnamc_ctx_destroy", "rnamc_ctx_set", "rnamc_ctx_set_params",
     "rnamc_bpp_batch", "rnamc_bpp_batch_device", "rnamc_ctx_last_stats", "rnamc_ctx_stats",
-    "rnamc_debug_fetch", "rnamc_fold_scores", "rnamc_centroid_fold", "rnamc_centroid_fold_multi",
+    "rnamc_debug_fetch", "rnamc_fold_scores", "rnamc_fold_sums", "rnamc_centroid_fold",
+    "rnamc_centroid_fold_multi",
     "rnamc_align_scores_new", "rnamc_align_scores_transfer", "rnamc_durbin_batch",
     "rnamc_pool_create", "rnamc_pool_destroy", "rnamc_pool_size", "rnamc_pool_ctx",
     "rnamc_pool_set_params", "rnamc_pool_set", "rnamc_bpp_batch_multi", "rnamc_shard_plan",
@@ -138,6 +139,7 @@ def lib():
     L.rnamc_fold_scores.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, vp, vp, vp, vp,
                                     C.c_uint64, u64p]
     L.rnamc_centroid_fold.argtypes = [vp, C.c_uint32, C.c_float, vp, C.c_uint32, u32p, f32p]
+    L.rnamc_fold_sums.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     L.rnamc_centroid_fold_multi.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp, vp]
     L.rnamc_align_scores_new.argtypes = [C.c_float, vp]
     L.rnamc_align_scores_transfer.argtypes = [vp]

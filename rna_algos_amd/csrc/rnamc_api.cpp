@@ -1595,6 +1595,57 @@ int rnamc_fold_scores(rnamc_ctx* c, const uint8_t* bases, uint32_t n, int uses_c
   return RNAMC_OK;
 }
 
+int rnamc_fold_sums(rnamc_ctx* c, const uint8_t* bases, uint32_t n, int uses_contra_model,
+                    int allows_short_hairpins, float* sums_external,
+                    float* sums_rightmost_basepairs_external,
+                    float* sums_rightmost_basepairs_multibranch, float* sums_close,
+                    float* sums_accessible, float* sums_multibranch,
+                    float* sums_1ormore_basepairs) {
+  if (!c || !bases) return RNAMC_ERR_INVALID_ARG;
+  if (n == 0) return RNAMC_ERR_EMPTY_SEQ;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  const uint64_t tri_len = rnamc_bpp_len(n);
+  // the inside sweep alone (reference order whatever the context's mode is), results left in
+  // the workspace; the fold-scores cache of the context is for another sequence afterwards
+  const uint64_t offsets[2] = {0, n}, out_offsets[2] = {0, 0};
+  c->fs_contra = c->fs_short = -1;
+  std::vector<float> packed(tri_len);
+  c->inside_only = true;
+  int rc = rnamc_bpp_batch(c, 1, bases, offsets, uses_contra_model, allows_short_hairpins,
+                           packed.data(), out_offsets, nullptr);
+  c->inside_only = false;
+  if (rc) return rc;
+  DeviceGuard guard(c->device);
+  if (!guard.ok) return RNAMC_ERR_NO_DEVICE;
+  const SeqDesc& sd = c->descs.back();
+  const float ninf = -std::numeric_limits<float>::infinity();
+  struct Want {
+    float* out;
+    int slot;       // workspace slot, or -1: the reference never writes this member in this model
+    float initial;  // the reference's initial value (FoldSums::new, 213-226)
+  };
+  const Want wants[7] = {
+      {sums_external, M_Z, 0.f},
+      {sums_rightmost_basepairs_external, M_ZRE, ninf},
+      {sums_rightmost_basepairs_multibranch, uses_contra_model ? M_ZRM : -1, ninf},
+      {sums_close, M_QB, ninf},
+      {sums_accessible, M_QA, ninf},
+      {sums_multibranch, M_QM, ninf},
+      {sums_1ormore_basepairs, M_Q1D, ninf},
+  };
+  for (const Want& w : wants) {
+    if (!w.out) continue;
+    for (uint64_t x = 0; x < static_cast<uint64_t>(n) * n; x++) w.out[x] = w.initial;
+    if (w.slot < 0) continue;
+    HIPCHK(hipMemcpy(packed.data(), c->d_ws + sd.ws_off + static_cast<uint64_t>(w.slot) * sd.tri_pad,
+                     tri_len * sizeof(float), hipMemcpyDeviceToHost));
+    uint64_t x = 0;  // diagonal-major: cell (i, i+d) at d*n - d(d-1)/2 + i
+    for (uint32_t d = 0; d < n; d++)
+      for (uint32_t i = 0; i + d < n; i++) w.out[static_cast<uint64_t>(i) * n + i + d] = packed[x++];
+  }
+  return RNAMC_OK;
+}
+
 int rnamc_centroid_fold_multi(rnamc_ctx* c, const float* bpp_packed, uint32_t n,
                               const float* centroid_thresholds, uint32_t n_thresholds,
                               uint32_t* pairs_out, uint32_t max_pairs, uint32_t* n_pairs,

@@ -106,6 +106,35 @@ class FoldScores:
     accessible_scores = property(lambda self: self._get(3))
 
 
+class FoldSums:
+    """Mirror of `FoldSums<T>` (src/mccaskill_algo.rs:3-11), the value of the reference's first
+    stage `get_fold_sums` / `get_fold_sums_contra` (282, 380).  The five dense members are n x n
+    f32 arrays with the reference's initial values where it writes nothing (sums_external 0,
+    the others -inf); `sums_close` and `sums_accessible`, hash maps in the reference, are
+    {(i, j): value} dicts of the finite entries (built on first use; the dense form with -inf =
+    absent is `dense["sums_close"]`)."""
+    FIELDS = ("sums_external", "sums_rightmost_basepairs_external",
+              "sums_rightmost_basepairs_multibranch", "sums_close", "sums_accessible",
+              "sums_multibranch", "sums_1ormore_basepairs")
+    SPARSE = ("sums_close", "sums_accessible")
+
+    def __init__(self, n, dense):
+        self.n = n
+        self.dense = dense
+        self._sparse = {}
+
+    def __getattr__(self, name):
+        if name in FoldSums.SPARSE:
+            if name not in self._sparse:
+                m = self.dense[name]
+                ii, jj = np.nonzero(np.isfinite(m))
+                self._sparse[name] = {(int(i), int(j)): float(m[i, j]) for i, j in zip(ii, jj)}
+            return self._sparse[name]
+        if name in FoldSums.FIELDS:
+            return self.dense[name]
+        raise AttributeError(name)
+
+
 class Context:
     """Owns one rnamc_ctx (tables + workspace on one GPU)."""
 
@@ -201,6 +230,18 @@ class Context:
         _lib.check(_lib.lib().rnamc_fold_scores(*args, tl.ctypes.data, count.value,
                                                 C.byref(count)))
         return n, hp, mb, ac, tl
+
+    def fold_sums(self, seq, uses_contra_model, allows_short_hairpins):
+        """FoldSums of one sequence (rnamc_fold_sums: the inside sweep alone, reference order)
+        -> FoldSums"""
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        n = int(seq.shape[0])
+        if n == 0:
+            raise _lib.RnamcError(_lib.ERR_EMPTY_SEQ)
+        mats = [np.empty((n, n), dtype=np.float32) for _ in FoldSums.FIELDS]
+        _lib.check(_lib.lib().rnamc_fold_sums(self._h, seq.ctypes.data, n, int(uses_contra_model),
+                                             int(allows_short_hairpins), *[m.ctypes.data for m in mats]))
+        return FoldSums(n, dict(zip(FoldSums.FIELDS, mats)))
 
     def debug_fetch(self, seq_idx, which, n):
         out = np.empty((n, n), dtype=np.float32)
@@ -322,6 +363,19 @@ def mccaskill_algo(seq, uses_contra_model, allows_short_hairpins, fold_score_set
 
 
 _pool = None
+
+
+def get_fold_sums(seq, fold_score_sets):
+    """`get_fold_sums<T>(seq, &mut fold_scores) -> FoldSums<T>` (src/mccaskill_algo.rs:282-378,
+    Turner) on the device.  The reference also fills `fold_scores` on the way; here that is
+    `mccaskill_algo(...)[1]` / `Context.fold_scores_packed`."""
+    return _context_for(fold_score_sets).fold_sums(seq, False, False)
+
+
+def get_fold_sums_contra(seq, allows_short_hairpins, fold_score_sets):
+    """`get_fold_sums_contra<T>(seq, &mut fold_scores, allows_short_hairpins, fold_score_sets)`
+    (src/mccaskill_algo.rs:380-516) on the device."""
+    return _context_for(fold_score_sets).fold_sums(seq, True, allows_short_hairpins)
 
 
 def _pool_for(fold_score_sets):

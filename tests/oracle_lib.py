@@ -25,6 +25,7 @@ def lib():
         vp = C.c_void_p
         L.rnamc_oracle_bpp.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, vp, vp]
         L.rnamc_oracle_bpp_dump.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, vp, vp, vp]
+        L.rnamc_oracle_fold_sums.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, vp]
         L.rnamc_oracle_bpp_batch.argtypes = [vp, C.c_uint32, vp, vp, C.c_int, C.c_int, vp, vp, vp,
                                              C.c_uint32]
         L.rnamc_oracle_exact_bpp.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, vp, vp]
@@ -78,6 +79,22 @@ def bpp_dump(params_ptr, seq, contra, short=False):
     _chk(lib().rnamc_oracle_bpp_dump(params_ptr, seq.ctypes.data, n, int(contra), int(short),
                                      out.ctypes.data, logz.ctypes.data, ptrs))
     return out, np.float32(logz[0]), mats
+
+
+FOLD_SUMS_FIELDS = ("sums_external", "sums_rightmost_basepairs_external",
+                    "sums_rightmost_basepairs_multibranch", "sums_close", "sums_accessible",
+                    "sums_multibranch", "sums_1ormore_basepairs")
+
+
+def fold_sums(params_ptr, seq, contra, short=False):
+    """get_fold_sums / get_fold_sums_contra (src/mccaskill_algo.rs:282, 380) -> dict of the seven
+    FoldSums members as n*n f32 (sparse maps dense, -inf = absent)"""
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    n = seq.shape[0]
+    mats = [np.empty((n, n), dtype=np.float32) for _ in range(7)]
+    ptrs = (C.c_void_p * 7)(*[m.ctypes.data for m in mats])
+    _chk(lib().rnamc_oracle_fold_sums(params_ptr, seq.ctypes.data, n, int(contra), int(short), ptrs))
+    return dict(zip(FOLD_SUMS_FIELDS, mats))
 
 
 def bpp_batch(params_ptr, seqs, contra, short=False, n_threads=1, want_bpp=True):

@@ -396,6 +396,41 @@ def test_fold_scores_match_reference_maps(ctx, params, trnas, contra, short):
         assert tl.tobytes() == rtl.tobytes()
 
 
+@pytest.mark.parametrize("contra,short", [(False, False), (True, False), (True, True)])
+def test_fold_sums_match_reference_stage(ctx, params, trnas, contra, short):
+    """FoldSums<T> (src/mccaskill_algo.rs:3-11), the value of the reference's first stage
+    `get_fold_sums{,_contra}` (282, 380): all seven members from rnamc_fold_sums equal the
+    oracle's stage bit for bit in every cell — written cells, the reference's initial values in
+    the cells it skips (sums_external 0, the others -inf, lower triangles included), absent keys
+    of the two sparse maps; lone sequences (latency forms) and n < 5 included."""
+    rng = np.random.default_rng(12)
+    seqs = [trnas[0][1], trnas[4][1], rng.integers(0, 4, 211).astype(np.uint8),
+            rng.integers(0, 2, 64).astype(np.uint8) * 3,  # A/U only
+            np.array([2, 1, 2, 1, 0, 0, 0, 0, 2, 1, 2, 1], np.uint8), np.array([0, 3, 0], np.uint8),
+            np.array([2], np.uint8)]
+    for seq in seqs:
+        got = ctx.fold_sums(seq, contra, short)
+        ref = O.fold_sums(params.ptr, seq, contra, short)
+        for name in O.FOLD_SUMS_FIELDS:
+            g, r = got.dense[name], ref[name]
+            assert g.shape == r.shape == (len(seq), len(seq))
+            assert np.array_equal(g.view(np.uint32), r.view(np.uint32)), \
+                f"{name}, n={len(seq)} contra={contra} short={short}: " \
+                f"{int((g.view(np.uint32) != r.view(np.uint32)).sum())} cells differ"
+        assert set(got.sums_close) == {(int(i), int(j)) for i, j in
+                                       zip(*np.nonzero(np.isfinite(ref["sums_close"])))}
+    # the stage functions of the mirror module, and the whole path after them on the same context
+    from rna_algos_amd.mccaskill_algo import get_fold_sums, get_fold_sums_contra
+    seq = seqs[0]
+    fs = get_fold_sums_contra(seq, short, params) if contra else get_fold_sums(seq, params)
+    ref = O.fold_sums(params.ptr, seq, contra, short if contra else False)
+    assert np.array_equal(fs.sums_external.view(np.uint32), ref["sums_external"].view(np.uint32))
+    mats, logz = ctx.bpp_batch([seq], contra, short)
+    rb, rz = O.bpp(params.ptr, seq, contra, short)
+    assert np.float32(logz[0]) == rz
+    assert_same(mats[0].packed, rb, "bpp after fold_sums on the same context")
+
+
 def test_mccaskill_algo_returns_fold_scores(params, trnas):
     """The mirror of the reference entry point returns (bpp map, FoldScores) with the maps
     filled like the reference's (lazily, on first access)."""

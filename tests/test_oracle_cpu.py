@@ -290,3 +290,30 @@ def test_logsumexp_pieces_never_lower_the_sum_by_more_than_rounding():
     # ln(1 + e^-11.86) = 7e-6: the pieces may undershoot z by at most their own error
     assert worst * 256 < 1.0, worst
     print(f"max (z - r(z)) over all pieces: {worst:.3e}  (x 256 steps = {worst * 256:.3e} < margin 1)")
+
+
+def test_fold_sums_stage_is_the_inside_pass_of_the_whole_path():
+    """rnamc_oracle_fold_sums (get_fold_sums{,_contra}, src/mccaskill_algo.rs:282 / 380) returns
+    what the whole path's inside pass leaves (bpp_dump's intermediates), with FoldSums::new's
+    initial values (213-226) where the reference writes nothing."""
+    from rna_algos_amd.utils import FoldScoreSets
+    P = FoldScoreSets.synthetic(1)
+    rng = np.random.default_rng(3)
+    for contra, short in ((False, False), (True, False), (True, True)):
+        for n in (1, 4, 5, 33, 90):
+            seq = rng.integers(0, 4, n).astype(np.uint8)
+            fs = O.fold_sums(P.ptr, seq, contra, short)
+            _, logz, mats = O.bpp_dump(P.ptr, seq, contra, short)
+            for name, w in (("sums_close", 0), ("sums_accessible", 1), ("sums_external", 2),
+                            ("sums_1ormore_basepairs", 3)):
+                assert np.array_equal(fs[name].view(np.uint32), mats[w].view(np.uint32)), (name, n, contra)
+            assert fs["sums_external"][0, n - 1] == logz
+            low = np.tril_indices(n, -1)
+            assert np.all(fs["sums_external"][low] == 0.0)
+            for name in O.FOLD_SUMS_FIELDS[1:]:
+                assert np.all(np.isneginf(fs[name][low])), name
+            if not contra:  # Turner never writes the multibranch flavour, nor spans below 5
+                assert np.all(np.isneginf(fs["sums_rightmost_basepairs_multibranch"]))
+                iu = np.triu_indices(n)
+                short_span = (iu[1] - iu[0]) < 4
+                assert np.all(fs["sums_external"][iu][short_span] == 0.0)
