@@ -1,0 +1,94 @@
+"""Randomised soak of the TREE-ORDER mode (rnamc_ctx_set "summation_mode" 1) against the f64
+evaluation of the same recurrences (oracle/mccaskill_exact.c): ragged batches, all three model
+variants, random tree knobs (threads per cell, band width, ahead role, one / two diagonals per
+launch), random table sets.  Per round: key sets identical, |dp| and |d ln Z| within the f32
+rounding of an order-free sum (bounds as in tests/test_gpu_tree.py, |dp| with twice the slope),
+identical bits when the same batch is run a second time (deterministic); whether a lone call of
+one member gives the batch's bits is printed (it may take another threads-per-cell variant).
+Test infrastructure, not collected by pytest; run on the GPU box:
+    python tests/soak_tree.py [rounds] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import oracle_lib as O  # noqa: E402
+from rna_algos_amd.utils import FoldScoreSets  # noqa: E402
+from rna_algos_amd.mccaskill_algo import Context  # noqa: E402
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2027)
+    bad = 0
+    worst_p = worst_z = 0.0
+    for r in range(rounds):
+        P = FoldScoreSets.synthetic(int(rng.integers(1, 50)))
+        ctx = Context(P, device=0)
+        knobs = {
+            "tree_tpc": int(rng.choice([0, 0, 64, 128, 256, 1024])),
+            "tree_band": int(rng.choice([0, 32, 64, 64, 96, 128])),
+            "tree_ahead": int(rng.integers(0, 2)),
+            "tree_two": int(rng.choice([0, 1, 1, 1])),
+            "group_max_seqs": int(rng.choice([1, 3, 17, 8192])),
+        }
+        ctx.set("summation_mode", 1)
+        for k, v in knobs.items():
+            ctx.set(k, v)
+        kind = int(rng.integers(0, 4))
+        if kind == 0:    # many short
+            lens = rng.integers(1, 120, int(rng.integers(20, 120)))
+        elif kind == 1:  # a few long ones: banded sweeps (n >= 3 band + 2)
+            lens = rng.integers(200, 700, int(rng.integers(2, 6)))
+        elif kind == 2:  # low-complexity and tiny
+            lens = rng.integers(1, 40, 30)
+        else:            # one lone sequence (use_one descriptors)
+            lens = rng.integers(100, 900, 1)
+        alphabet = int(rng.choice([2, 3, 4, 4, 4]))
+        seqs = [rng.integers(0, alphabet, int(n)).astype(np.uint8) for n in lens]
+        contra, short = [(False, False), (True, False), (True, True)][int(rng.integers(0, 3))]
+        mats, logz = ctx.bpp_batch(seqs, contra, short)
+        again, logz2 = ctx.bpp_batch(seqs, contra, short)
+        ok = all(np.array_equal(np.asarray(a.packed).view(np.uint32), np.asarray(b.packed).view(np.uint32))
+                 for a, b in zip(mats, again)) and \
+            np.array_equal(np.asarray(logz).view(np.uint32), np.asarray(logz2).view(np.uint32))
+        why = "" if ok else " NOT DETERMINISTIC"
+        lone = int(rng.integers(0, len(seqs)))
+        m1, z1 = ctx.bpp_batch([seqs[lone]], contra, short)
+        same_alone = np.array_equal(np.asarray(m1[0].packed).view(np.uint32),
+                                    np.asarray(mats[lone].packed).view(np.uint32))
+        # (a lone call may take other threads-per-cell variants than the batch: same sums in
+        # another association; bounded like the rest, not bit-compared)
+        dp_round = dz_round = 0.0
+        for s, m, lz in zip(seqs, mats, logz):
+            xb, xz = O.exact_bpp(P.ptr, s, contra, short)
+            got = np.asarray(m.packed, dtype=np.float64)
+            kg, kx = got >= -0.5, xb >= -0.5
+            if not np.array_equal(kg, kx):
+                ok = False
+                why += f" KEYS(n={len(s)})"
+                continue
+            dp = float(np.max(np.abs(got[kg] - xb[kg]))) if kg.any() else 0.0
+            dz = abs(float(lz) - xz)
+            dp_round, dz_round = max(dp_round, dp), max(dz_round, dz)
+            # (table sets of other seeds reach larger |ln Z| per nucleotide than seed 1, whose
+            # bound tests/test_gpu_tree.py uses: twice its slope here)
+            if dp > 2e-5 + 4e-7 * len(s) or dz > 2e-5 + 3e-6 * abs(xz):
+                ok = False
+                why += f" BOUND(n={len(s)} dp={dp:.2e} dz={dz:.2e})"
+        worst_p, worst_z = max(worst_p, dp_round), max(worst_z, dz_round)
+        bad += not ok
+        print(f"round {r}: {'ok ' if ok else 'BAD'}{why} seqs={len(seqs)} max_n={int(lens.max())} "
+              f"contra={contra} short={short} dp={dp_round:.1e} dlnZ={dz_round:.1e} "
+              f"lone_bitwise={'same' if same_alone else 'differs'} {knobs}", flush=True)
+        ctx.close()
+    print(f"tree soak: {'all ok' if bad == 0 else str(bad) + ' BAD rounds'}; worst |dp| {worst_p:.2e}, "
+          f"worst |d ln Z| {worst_z:.2e}")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
