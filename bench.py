@@ -188,6 +188,15 @@ def tree_leg(ctx, torch, dev, stream, seq, contra, reps, f, ref=None):
         ctx.set("summation_mode", 0)
     med = float(np.median(ms))
     by = tree_bytes(n, f, contra)
+    # HBM bytes of the whole sweep from the committed PMC passes (scripts/prof_tree.sh: FETCH_SIZE
+    # doubled as the gfx950 guide prescribes, + WRITE_SIZE), n = 4096 Turner only
+    traffic = traffic_src = None
+    if n == 4096 and not contra:
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", "r03_tree_n4096_traffic.json")))
+            traffic, traffic_src = float(t["total_bytes_x2"]), "profiles/r03_tree_n4096_traffic.json"
+        except Exception:
+            pass
     res = {
         "ms_per_seq": med, "ms_all_calls": [round(x, 2) for x in ms],
         "ms_inside": st["ms_inside"], "ms_outside": st["ms_outside"],
@@ -198,7 +207,8 @@ def tree_leg(ctx, torch, dev, stream, seq, contra, reps, f, ref=None):
             "kernel": "k_tree_inside2 + k_tree_outside2 (whole sweep, two anti-diagonals per launch) with "
                       "k_tree_mid / k_tree_ext beside them (banded mid-field, second stream)",
             "bound": "hbm", "achieved": by["b_8d"] / (med * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": by["b_8d"] / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "unit": "GB/s", "frac": by["b_8d"] / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": traffic_src,
             "bytes": "SURVEY 8d streamed-operand model of the reference's loops "
                      "([16 + 8 + 12 f] T + 12*496 f n^2/2 + 36 n^2)",
             "algorithmic_bytes": by["b_8d"],
