@@ -140,6 +140,40 @@ __device__ __forceinline__ float lse(float sum, float x, const LseTab* tab) {
   return (lo == kNegInf) ? hi : r;
 }
 
+// The same fold step with a WAVE-UNIFORM fast path for the outside chains.  Measured on the 512
+// longest sequences of the bench batch (profiles/r04_wave_uniform_far.txt): in 62 % of the fold
+// steps of the pair-probability tail and 64 % of those of probs_multibranch (53 % under
+// CONTRAfold) EVERY lane of the wave either meets the identity piece (z >= 11.862479,
+// src/utils.rs:589-591) or folds a -inf operand.  One compare + a scalar branch on its ballot
+// then replaces the two dependent LDS lookups and the cubic by the reference's own two operations
+// `lo + (hi - lo)`; lanes with lo = -inf take hi (src/utils.rs:581-586).  Bit-identical by
+// construction: piece 8 of the table evaluates ((0*z+0)*z+1)*z+0 = z.  (z is NaN only when both
+// operands are -inf: `z < t` is false, the lane counts as far, and the select returns hi = -inf.)
+#ifndef RNAMC_LSE_WU
+#define RNAMC_LSE_WU 1
+#endif
+__device__ __forceinline__ float lse_wu(float sum, float x, const LseTab* tab) {
+#if RNAMC_LSE_WU
+  const float hi = vmax(sum, x);
+  const float lo = vmin(sum, x);
+  const float z = hi - lo;
+  if (__ballot(z < 11.862479f) == 0ull) {
+    const float r = lo + z;
+    return (lo == kNegInf) ? hi : r;
+  }
+  const int e = static_cast<int>(__float_as_uint(z) >> 20);
+  const int cell = min(max(e, kLseCellLo), kLseCellHi) - kLseCellLo;
+  const float2 ce = tab->cell[cell];
+  const uint32_t boff = __float_as_uint(ce.y) + ((z >= ce.x) ? 16u : 0u);
+  const float4 co = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tab) + boff);
+  float r = ((co.x * z + co.y) * z + co.z) * z + co.w;
+  r = lo + r;
+  return (lo == kNegInf) ? hi : r;
+#else
+  return lse(sum, x, tab);
+#endif
+}
+
 __device__ __forceinline__ float expf_ref(float x) {
   if (x < -2.4915035f) {
     if (x < -5.8622823f) {
@@ -166,6 +200,52 @@ __device__ __forceinline__ float expf_ref(float x) {
     return static_cast<float>(exp(static_cast<double>(x)));
   }
 }
+
+#ifdef RNAMC_COUNT_FAR
+// Counting build only (make COUNT_FAR=1 -> librnamc_count.so, scripts/count_far.py): how often a
+// whole WAVE of the outside chains meets the identity piece of logsumexp (z >= 11.862479, or the
+// smaller operand -inf) in the same fold step — the condition under which a wave-uniform fast
+// path could skip the table lookups and the cubic.  Never part of the product library.
+//   [role][0] fold steps executed by a wave     [1] ... with every lane on the identity piece / -inf
+//   [2] ... with every lane's TERM -inf (no-op)  [3] lane-steps on the identity piece / -inf
+//   [4] lane-steps whose term is -inf            [5] k-steps (all folds of one k) executed by a wave
+//   [6] ... all of them wave-uniform far         [7] chunks of 16 k (pair tail) / 8 k (mb) [8] ... all far
+// role 0 = pair tail (k_outside<.,2> / the tail role of <.,7>), 1 = probs_multibranch
+__device__ unsigned long long g_far_counters[2][16];
+struct FarCount {
+  uint32_t c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  bool kfar = true, cfar = true;
+  __device__ __forceinline__ void fold(float sum, float x) {
+    const float hi = fmaxf(sum, x), lo = fminf(sum, x);
+    const float z = hi - lo;
+    const bool far = !(z < 11.862479f);  // identity piece; lo = -inf gives z = +inf or NaN
+    const bool skip = !(x > kNegInf);
+    const unsigned long long all = __ballot(true);
+    const unsigned long long mf = __ballot(far), ms = __ballot(skip);
+    c[0]++;
+    c[1] += (mf == all) ? 1u : 0u;
+    c[2] += (ms == all) ? 1u : 0u;
+    c[3] += static_cast<uint32_t>(__popcll(mf));
+    c[4] += static_cast<uint32_t>(__popcll(ms));
+    kfar = kfar && (mf == all);
+  }
+  __device__ __forceinline__ void end_k() {
+    c[5]++;
+    c[6] += kfar ? 1u : 0u;
+    cfar = cfar && kfar;
+    kfar = true;
+  }
+  __device__ __forceinline__ void end_chunk() {
+    c[7]++;
+    c[8] += cfar ? 1u : 0u;
+    cfar = true;
+  }
+  __device__ __forceinline__ void flush(int role) {
+    if ((threadIdx.x & 63u) == 0u)
+      for (int x = 0; x < 9; x++) atomicAdd(&g_far_counters[role][x], static_cast<unsigned long long>(c[x]));
+  }
+};
+#endif
 
 // ----------------------------------------------------------------------------
 // index algebra
@@ -1015,12 +1095,20 @@ __device__ __forceinline__ void outside_mb_cell(const DeviceBatch& b, const Seq&
   // partners of base a as a 4-bit set: A:{U} C:{G} G:{C,U} U:{A,G}
   const uint32_t pairmask = valid ? (0x5A48u >> (4u * q.s[i])) & 15u : 0u;
   float pm = kNegInf, pm2 = kNegInf;
+#ifdef RNAMC_COUNT_FAR
+  FarCount fc;
+#endif
   auto step = [&](float x, float r, uint32_t t) {
-    pm = lse(pm, x + r, tab);
+#ifdef RNAMC_COUNT_FAR
+    fc.fold(pm, x + r);
+    fc.fold(pm2, CONTRA ? x + mun * static_cast<float>(t - 1) : x);
+    fc.end_k();
+#endif
+    pm = lse_wu(pm, x + r, tab);
     if (CONTRA) {
-      pm2 = lse(pm2, x + mun * static_cast<float>(t - 1), tab);
+      pm2 = lse_wu(pm2, x + mun * static_cast<float>(t - 1), tab);
     } else {
-      pm2 = lse(pm2, x, tab);
+      pm2 = lse_wu(pm2, x, tab);
     }
   };
   struct DAux {
@@ -1073,6 +1161,9 @@ __device__ __forceinline__ void outside_mb_cell(const DeviceBatch& b, const Seq&
 #pragma unroll
     for (int u = 0; u < kU; u++)
       step(((B.bits >> u) & 1u) ? B.xs[u] : kNegInf, B.rs[u], t0 + u);
+#ifdef RNAMC_COUNT_FAR
+    fc.end_chunk();
+#endif
   };
   auto single = [&](uint32_t t, float& x) {  // one step outside the pipeline
     const uint32_t bit = 2u * (j + t + 32u);
@@ -1127,6 +1218,9 @@ __device__ __forceinline__ void outside_mb_cell(const DeviceBatch& b, const Seq&
     single(t, x);
     step(x, ldu(q1d + tri_off(n, t - 2) + d + 1, i4), t);
   }
+#ifdef RNAMC_COUNT_FAR
+  fc.flush(1);
+#endif
   if (valid) {
     // {probs_multibranch, probs_multibranch2} interleaved: 16 k-steps of a column = one
     // 128-byte line (slots PM and PM2 are adjacent and form one float2 array)
@@ -1207,18 +1301,34 @@ __device__ __forceinline__ void outside_pair_tail(const DeviceBatch& b, const Se
       reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(q.m[M_PM]) + col_off(j));
   const float4* __restrict__ xcol =
       reinterpret_cast<const float4*>(q.m[M_Q1C] + col_off(i >= 1 ? i - 1 : 0));
+#ifdef RNAMC_COUNT_FAR
+  FarCount fc;
+#endif
   auto step = [&](float x, float y, float y2, uint32_t k) {
     const bool vy = k < iend;
     x = (k + 2 <= iend) ? x : kNegInf;
     y = vy ? y : kNegInf;
     y2 = vy ? y2 : kNegInf;
-    p = lse(p, sa + y2 + x, tab);
+#ifdef RNAMC_COUNT_FAR
+    fc.fold(p, sa + y2 + x);
+#endif
+    p = lse_wu(p, sa + y2 + x, tab);
     if (CONTRA) {
-      p = lse(p, sa + y + mun * static_cast<float>(i - k - 1), tab);
+#ifdef RNAMC_COUNT_FAR
+      fc.fold(p, sa + y + mun * static_cast<float>(i - k - 1));
+#endif
+      p = lse_wu(p, sa + y + mun * static_cast<float>(i - k - 1), tab);
     } else {
-      p = lse(p, sa + y, tab);
+#ifdef RNAMC_COUNT_FAR
+      fc.fold(p, sa + y);
+#endif
+      p = lse_wu(p, sa + y, tab);
     }
-    p = lse(p, sa + x + y, tab);
+#ifdef RNAMC_COUNT_FAR
+    fc.fold(p, sa + x + y);
+    fc.end_k();
+#endif
+    p = lse_wu(p, sa + x + y, tab);
   };
   // Chunks of 16 k-steps.  A 128-byte line holds 16 steps of {y, y2} and 32 steps of x; a
   // lane fetches whole lines of its own columns (64-byte pieces read 11 % slower) into ONE
@@ -1250,8 +1360,14 @@ __device__ __forceinline__ void outside_pair_tail(const DeviceBatch& b, const Se
         for (int u = 0; u < 8; u++) yl[u] = yycol[k / 2 + u];
       }
       if ((c & 1u) == 0u) fold16l(&xl[0], yl, k); else fold16l(&xl[4], yl, k);
+#ifdef RNAMC_COUNT_FAR
+      fc.end_chunk();
+#endif
     }
   }
+#ifdef RNAMC_COUNT_FAR
+  fc.flush(0);
+#endif
   if (paired && p > kNegInf) {
     q.m[M_P][od] = p;
     reinterpret_cast<float2*>(q.m[M_PQ])[od] = make_float2(p, qb_ij);
@@ -1834,3 +1950,15 @@ void launch_finalize(const DeviceBatch& b, uint32_t nseq, uint32_t max_n, uint32
 
 }  // namespace rnamc
 
+#ifdef RNAMC_COUNT_FAR
+// counting build only: copy (and optionally clear) the tallies of FarCount
+extern "C" int rnamc_debug_far_counters(unsigned long long* out32, int reset) {
+  if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(rnamc::g_far_counters), sizeof(unsigned long long) * 32) != hipSuccess)
+    return 7;
+  if (reset) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(rnamc::g_far_counters), z, sizeof(z)) != hipSuccess) return 7;
+  }
+  return 0;
+}
+#endif

@@ -1,7 +1,10 @@
 """Generates tests/golden/*.json|npz from the CPU oracle with the seeded synthetic
 tables ("self-golden, synthetic tables": the reference itself cannot run here and
 holds no golden vectors for this path — SURVEY.md §8c).  Usage:
-    python tests/make_golden.py [small|container|batch|batch2k|n1024|n4096_turner|n4096_contra]
+    python tests/make_golden.py [small|container|batch|batch2k|n1024|n4096_turner|n4096_contra|exact|exact4096]
+`exact` writes the f64 fixtures of the tree-order mode (oracle/mccaskill_exact.c: the oracle's own
+loops with Score = double and an exact logsumexp): ln Z, the probability of every 97th present
+pair and the sha256 of the key set, for n = 1024 (both models, seed 1024) and n = 2048 Turner.
 """
 import hashlib
 import json
@@ -19,6 +22,7 @@ from rna_algos_amd.utils import FoldScoreSets, read_fasta  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 PARAM_SEED = 1
+EXACT_STRIDE = 97  # every 97th present pair (packed diagonal-major order) goes into a fixture
 
 
 def digest(packed):
@@ -91,6 +95,31 @@ def main(which):
             with open(os.path.join(GOLD, "checksums_batch2k.json"), "w") as fh:
                 json.dump({"param_seed": PARAM_SEED, "batch_count": 10000, "cases": res}, fh, indent=1)
         print(json.dumps(res, indent=1))
+        return
+    if which in ("exact", "exact4096"):
+        # (exact4096: BASELINE.json configs[2], n = 4096 Turner — about 40 minutes of one core)
+        for n, seed, contra in (((1024, 1024, 1), (1024, 1024, 0), (2048, 2048, 0)) if which == "exact"
+                                else ((4096, 4096, 0),)):
+            s = O.splitmix_seq(n, seed)
+            t0 = time.time()
+            xb, xz = O.exact_bpp(P.ptr, s, contra, 0)
+            secs = time.time() - t0
+            pres = np.flatnonzero(xb >= -0.5)
+            pick = pres[::EXACT_STRIDE]
+            name = f"exact_n{n}_seed{seed}_{'contra' if contra else 'turner'}"
+            np.savez_compressed(os.path.join(GOLD, name + ".npz"),
+                                n=np.array([n], np.int64), seed=np.array([seed], np.int64),
+                                contra=np.array([contra], np.int64),
+                                param_seed=np.array([PARAM_SEED], np.int64),
+                                log_partition=np.array([xz], np.float64),
+                                present=np.array([pres.size], np.int64),
+                                keyset_sha256=np.frombuffer(
+                                    hashlib.sha256(pres.astype(np.uint32).tobytes()).digest(), np.uint8),
+                                index=pick.astype(np.uint32), prob=xb[pick].astype(np.float64),
+                                max_prob=np.array([xb[pres].max()], np.float64),
+                                sum_present=np.array([xb[pres].sum()], np.float64),
+                                oracle_seconds=np.array([secs], np.float64))
+            print(name, "ln Z", xz, "present", pres.size, "picked", pick.size, f"{secs:.1f} s", flush=True)
         return
     cases = {"n1024": [(1024, 1024, 1), (1024, 1024, 0)], "n4096_turner": [(4096, 4096, 0)],
              "n4096_contra": [(4096, 4096, 1)]}[which]

@@ -118,6 +118,46 @@ def test_tree_vs_reference_order_keys_and_deviation(ctx, params, trnas, contra):
         assert pres.min() >= -0.001 and pres.max() < 1.001  # the reference's own assertion
 
 
+def load_exact(name):
+    """f64 fixture of tests/make_golden.py `exact` (oracle/mccaskill_exact.c): ln Z, the probability of
+    every 97th present pair (packed diagonal-major index), the sha256 of the key set."""
+    import hashlib
+    import os
+    f = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    return f, hashlib
+
+
+EXACT_FIXTURES = ["exact_n1024_seed1024_contra", "exact_n1024_seed1024_turner", "exact_n2048_seed2048_turner",
+                  "exact_n4096_seed4096_turner"]
+
+
+@pytest.mark.parametrize("name", EXACT_FIXTURES)
+def test_tree_vs_committed_exact_f64(ctx, params, name):
+    """The tree-order mode pinned AT SCALE (round-3 verdict, missing 4): n = 1024 both models, n = 2048
+    and n = 4096 Turner against committed f64 evaluations of the recurrences — many bands of the
+    banded sweep, ring wrap-arounds at depth, every kernel of the mode.  Bounds as at n <= 410
+    (test_tree_vs_exact_f64): |dp| <= 2e-5 + 2e-7 n, |d ln Z| <= 2e-5 + 3e-6 |ln Z|, key set equal."""
+    import os
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", name + ".npz")):
+        pytest.skip(f"{name}.npz not generated (python tests/make_golden.py exact|exact4096)")
+    f, hashlib = load_exact(name)
+    n, seed, contra = int(f["n"][0]), int(f["seed"][0]), bool(f["contra"][0])
+    s = O.splitmix_seq(n, seed)
+    m, z = run(ctx, [s], contra, False, 1)
+    p = np.asarray(m[0].packed)
+    pres = np.flatnonzero(p >= -0.5)
+    assert pres.size == int(f["present"][0])
+    assert hashlib.sha256(pres.astype(np.uint32).tobytes()).digest() == bytes(f["keyset_sha256"]), "key set differs"
+    dp = float(np.max(np.abs(p[f["index"]].astype(np.float64) - f["prob"])))
+    dz = abs(float(z[0]) - float(f["log_partition"][0]))
+    print(f"{name}: tree-order vs committed f64: max |dp| = {dp:.3e} over {f['index'].size} pairs, "
+          f"|d ln Z| = {dz:.3e} (ln Z = {float(f['log_partition'][0]):.4f})")
+    assert dp <= 2e-5 + 2e-7 * n
+    assert dz <= 2e-5 + 3e-6 * abs(float(f["log_partition"][0]))
+    # sum over the sampled pairs as a second, aggregate check (no cancellation hides a bias)
+    assert abs(float(p[f["index"]].astype(np.float64).sum()) - float(f["prob"].sum())) <= 1e-5 * f["index"].size ** 0.5 + 1e-4
+
+
 def test_tree_n4096_turner(ctx, params):
     """BASELINE.json configs[2] in tree-order mode: key set of the parity gate, deviation
     printed and bounded, row sums, deterministic."""

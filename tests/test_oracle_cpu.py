@@ -317,3 +317,20 @@ def test_fold_sums_stage_is_the_inside_pass_of_the_whole_path():
                 iu = np.triu_indices(n)
                 short_span = (iu[1] - iu[0]) < 4
                 assert np.all(fs["sums_external"][iu][short_span] == 0.0)
+
+
+def test_exact_fixture_reproduces(params):
+    """tests/golden/exact_n1024_seed1024_contra.npz (the f64 pin of the tree-order mode at scale,
+    tests/make_golden.py `exact`) is what oracle/mccaskill_exact.c gives today: drift guard of the
+    fixture and of its container (every 97th present pair, key-set sha256).  ~30 s."""
+    f = np.load(os.path.join(GOLD, "exact_n1024_seed1024_contra.npz"))
+    n, seed = int(f["n"][0]), int(f["seed"][0])
+    xb, xz = O.exact_bpp(params.ptr, O.splitmix_seq(n, seed), 1, 0)
+    pres = np.flatnonzero(xb >= -0.5)
+    assert hashlib.sha256(pres.astype(np.uint32).tobytes()).digest() == bytes(f["keyset_sha256"])
+    assert np.array_equal(pres[::97], f["index"])
+    assert np.allclose(xb[f["index"]], f["prob"], rtol=0, atol=1e-13) and abs(xz - float(f["log_partition"][0])) < 1e-9
+    # and the f32 reference-order oracle sits where DESIGN.md section 4b says it does against it
+    out, lz = O.bpp(params.ptr, O.splitmix_seq(n, seed), 1, 0)
+    dp = float(np.max(np.abs(out[f["index"]].astype(np.float64) - f["prob"])))
+    assert 1e-4 < dp < 5e-2 and abs(float(lz) - xz) < 5e-2, (dp, float(lz), xz)
