@@ -242,7 +242,10 @@ int rnamc_ctx_set_params(rnamc_ctx* ctx, const rnamc_params* params);
  * the tiled kernel k_tree_mid one band ahead: 0 / 32 / 64 / 96 / 128, default 64; 0 = every launch
  * walks its sums whole), "tree_mid_wgs" (workgroups of a mid-field launch, default 256),
  * "tree_ahead" (banded sweeps: the far part of a launch's 2-loop blocks is summed by extra
- * workgroups of the previous launch, default 1). */
+ * workgroups of the previous launch, default 1), "tree_waves" (waves a tree-order launch may hold
+ * at once when it picks threads per cell, default 5120), "tree_short" (sums of at most this many
+ * terms take one wave per cell, default 256), "tree_ahead_waves" (waves up to which the ahead role
+ * takes one wave per cell instead of one per row, default 2^30).  Every knob is per context. */
 int rnamc_ctx_set(rnamc_ctx* ctx, const char* name, int64_t value);
 
 /* mccaskill_algo over a batch (src/mccaskill_algo.rs:247-280 for each record, as
@@ -302,6 +305,14 @@ int rnamc_bpp_batch_multi(rnamc_pool* pool, uint32_t n_seqs, const uint8_t* base
  * stable); cuts lie where the running cost a*n(n^2-1)/6 + b*n^2 reaches k/n_shards of the total. */
 int rnamc_shard_plan(uint32_t n_seqs, const uint64_t* offsets, uint32_t n_shards,
                      uint32_t* shard_of_seq);
+/* The cost model behind the partition, seconds of one reference-order sweep of an n-nt sequence
+ * on an MI355X: RNAMC_COST_S_PER_CELL_K * n(n^2-1)/6 (the Theta(n^3) folds) +
+ * RNAMC_COST_S_PER_N2 * n^2 (the 496-probe 2-loop blocks); fitted on one box (DESIGN.md section
+ * 6).  THE one source of the two constants: rnamc_shard_plan, bench.py's shards and
+ * rna_algos_amd.workloads.sweep_cost all evaluate rnamc_sweep_cost. */
+#define RNAMC_COST_S_PER_CELL_K 3.25e-12
+#define RNAMC_COST_S_PER_N2 6.6e-10
+int rnamc_sweep_cost(uint32_t count, const uint64_t* lengths, double* cost_s);
 
 /* Per-kernel accounting of the last batch call on this ctx (launch counts and
  * device time by HIP events on the launch stream; the latter only when

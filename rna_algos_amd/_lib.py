@@ -29,6 +29,7 @@ SYMBOLS = [
     "rnamc_align_scores_new", "rnamc_align_scores_transfer", "rnamc_durbin_batch",
     "rnamc_pool_create", "rnamc_pool_destroy", "rnamc_pool_size", "rnamc_pool_ctx",
     "rnamc_pool_set_params", "rnamc_pool_set", "rnamc_bpp_batch_multi", "rnamc_shard_plan",
+    "rnamc_sweep_cost",
 ]
 
 
@@ -135,6 +136,7 @@ def lib():
     L.rnamc_pool_set.argtypes = [vp, C.c_char_p, C.c_int64]
     L.rnamc_bpp_batch_multi.argtypes = [vp, C.c_uint32, vp, vp, C.c_int, C.c_int, vp, vp, vp]
     L.rnamc_shard_plan.argtypes = [C.c_uint32, vp, C.c_uint32, vp]
+    L.rnamc_sweep_cost.argtypes = [C.c_uint32, vp, vp]
     L.rnamc_debug_fetch.argtypes = [vp, C.c_uint32, C.c_int, vp]
     L.rnamc_fold_scores.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, vp, vp, vp, vp,
                                     C.c_uint64, u64p]

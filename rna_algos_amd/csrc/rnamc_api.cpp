@@ -79,6 +79,7 @@ struct rnamc_ctx {
   // tree mode, banded sweeps: the far part of a launch's 2-loop blocks is summed by extra
   // workgroups of the previous launch (rnamc_tree.hip, Ahead)
   int64_t tree_ahead = 1;
+  TreePolicy tree_pol;  // launch shapes of the tree-order sweep ("tree_waves", "tree_short", ...)
   hipStream_t bulk_stream = nullptr;  // k_tree_mid, beside the sweep (lowest priority)
   int64_t tree_debug = 0;  // (RNAMC_DEBUG_KNOBS builds: bit 0 no 2-loops, 1 no products, 2 empty kernels)
   int64_t group_max_seqs = 8192;
@@ -867,7 +868,7 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
 #ifdef RNAMC_DEBUG_KNOBS
         if (!(c->tree_debug & 32))  // (timing: the sweep without its mid-field kernels; results wrong)
 #endif
-        launch_tree_mid(b, outside, dlo, dhi, thr, gmax, active(dlo), c->bulk_stream);
+        launch_tree_mid(b, outside, dlo, dhi, thr, gmax, active(dlo), c->tree_pol, c->bulk_stream);
         HIPCHK(hipEventRecord(c->ev_b[x % ering], c->bulk_stream));
         c->stats.launches_other++;
         return RNAMC_OK;
@@ -905,7 +906,7 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
         // the next launch's diagonals: their 2-loop blocks' far parts ride in this launch
         const uint32_t nd0 = d + (pair ? 2u : 1u);
         const uint32_t ndc = (!ahead || nd0 >= gmax) ? 0u : ((nd0 % 2u == 0u && nd0 + 1 < gmax) ? 2u : 1u);
-        launch_tree_inside(b, contra, d, gmax, active(d), c->tree_tpc, pair, thr, use_far, nd0, ndc, st);
+        launch_tree_inside(b, contra, d, gmax, active(d), c->tree_tpc, pair, thr, use_far, nd0, ndc, c->tree_pol, st);
         use_far = ndc != 0u;
         c->stats.launches_inside++;
         d += pair ? 2 : 1;
@@ -953,14 +954,14 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
         }
         // (sequences that enter the sweep with the next launch need their far parts too)
         launch_tree_outside(b, contra, lower, gmax, active(ndc ? nd0 : lower), c->tree_tpc, pair, thr, use_far,
-                            nd0, ndc, st);
+                            nd0, ndc, c->tree_pol, st);
         use_far = ndc != 0u;
         dd -= pair ? 2 : 1;
         c->stats.launches_outside++;
       }
     } else {
     for (uint32_t d = dmin_in; d < gmax; d += two ? 2 : 1) {
-      launch_tree_inside(b, contra, d, gmax, active(d), c->tree_tpc, two, 0u, false, 0u, 0u, st);
+      launch_tree_inside(b, contra, d, gmax, active(d), c->tree_tpc, two, 0u, false, 0u, 0u, c->tree_pol, st);
       c->stats.launches_inside++;
     }
     if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 1], st));
@@ -971,17 +972,17 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
       int64_t d = static_cast<int64_t>(gmax) - 1;
       for (; d - 1 >= static_cast<int64_t>(dmin_out); d -= 2) {
         launch_tree_outside(b, contra, static_cast<uint32_t>(d - 1), gmax, active(static_cast<uint32_t>(d - 1)),
-                            c->tree_tpc, true, 0u, false, 0u, 0u, st);
+                            c->tree_tpc, true, 0u, false, 0u, 0u, c->tree_pol, st);
         c->stats.launches_outside++;
       }
       if (d >= static_cast<int64_t>(dmin_out)) {
         launch_tree_outside(b, contra, static_cast<uint32_t>(d), gmax, active(static_cast<uint32_t>(d)),
-                            c->tree_tpc, false, 0u, false, 0u, 0u, st);
+                            c->tree_tpc, false, 0u, false, 0u, 0u, c->tree_pol, st);
         c->stats.launches_outside++;
       }
     } else
     for (uint32_t d = gmax; d-- > dmin_out;) {
-      launch_tree_outside(b, contra, d, gmax, active(d), c->tree_tpc, false, 0u, false, 0u, 0u, st);
+      launch_tree_outside(b, contra, d, gmax, active(d), c->tree_tpc, false, 0u, false, 0u, 0u, c->tree_pol, st);
       c->stats.launches_outside++;
     }
     }
@@ -1214,13 +1215,13 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
   if (k == "summation_mode" && (value == 0 || value == 1)) {
     c->summation_mode = value;
   } else if (k == "tree_waves" && value >= 64) {
-    tree_policy(value, 0);
+    c->tree_pol.waves = static_cast<uint64_t>(value);
   } else if (k == "tree_short" && value >= 1) {
-    tree_policy(0, value);
+    c->tree_pol.short_terms = static_cast<uint32_t>(std::min<int64_t>(value, 1 << 30));
   } else if (k == "tree_mid_wgs" && value >= 1) {
-    tree_mid_policy(value);
+    c->tree_pol.mid_wgs = static_cast<uint32_t>(std::min<int64_t>(value, 1 << 20));
   } else if (k == "tree_ahead_waves" && value >= 0) {
-    tree_ahead_policy(value);
+    c->tree_pol.ahead_waves = static_cast<uint64_t>(value);
   } else if (k == "tree_ahead") {
     c->tree_ahead = value;
   } else if (k == "tree_two") {
@@ -1496,7 +1497,8 @@ int rnamc_ctx_stats(rnamc_ctx* c, void* out, uint64_t out_bytes, uint64_t* lib_b
   if (!c || (!out && out_bytes)) return RNAMC_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lock(c->mu);
   if (lib_bytes) *lib_bytes = sizeof(rnamc_batch_stats);
-  std::memcpy(out, &c->stats, static_cast<size_t>(std::min<uint64_t>(out_bytes, sizeof(rnamc_batch_stats))));
+  if (out && out_bytes)
+    std::memcpy(out, &c->stats, static_cast<size_t>(std::min<uint64_t>(out_bytes, sizeof(rnamc_batch_stats))));
   return RNAMC_OK;
 }
 
@@ -1603,13 +1605,20 @@ int rnamc_fold_sums(rnamc_ctx* c, const uint8_t* bases, uint32_t n, int uses_con
                     float* sums_1ormore_basepairs) {
   if (!c || !bases) return RNAMC_ERR_INVALID_ARG;
   if (n == 0) return RNAMC_ERR_EMPTY_SEQ;
+  if (n > RNAMC_MAX_SEQ_LEN) return RNAMC_ERR_SEQ_TOO_LONG;  // (before anything is sized by n)
   std::lock_guard<std::recursive_mutex> lock(c->mu);
   const uint64_t tri_len = rnamc_bpp_len(n);
   // the inside sweep alone (reference order whatever the context's mode is), results left in
   // the workspace; the fold-scores cache of the context is for another sequence afterwards
   const uint64_t offsets[2] = {0, n}, out_offsets[2] = {0, 0};
   c->fs_contra = c->fs_short = -1;
-  std::vector<float> packed(tri_len);
+  std::vector<float> packed;
+  try {  // nothing may throw across the C boundary
+    packed.resize(tri_len);
+  } catch (const std::exception&) {
+    rnamc::set_last_error("rnamc_fold_sums: no host memory for a packed triangle");
+    return RNAMC_ERR_OOM;
+  }
   c->inside_only = true;
   int rc = rnamc_bpp_batch(c, 1, bases, offsets, uses_contra_model, allows_short_hairpins,
                            packed.data(), out_offsets, nullptr);

@@ -139,6 +139,14 @@ struct TreeBatch {
   int debug;  // timing experiments (builds with -DRNAMC_DEBUG_KNOBS only; 0 otherwise)
   uint32_t ring;  // diagonals the mid-field ring holds (twice the band width; 0: no banding)
 };
+// Launch-shape policy of the tree-order sweep, per context (rnamc_ctx_set "tree_waves",
+// "tree_short", "tree_ahead_waves", "tree_mid_wgs"): passed to every launch, no process globals.
+struct TreePolicy {
+  uint64_t waves = 5120;            // waves a launch may hold at once (5 per SIMD at ~88 VGPRs)
+  uint32_t short_terms = 256;       // sums up to this many terms take one wave per cell
+  uint64_t ahead_waves = 1u << 30;  // waves up to which the ahead role takes one wave per CELL
+  uint32_t mid_wgs = 256;           // workgroups of a k_tree_mid launch
+};
 // what = 0: everything before the inside sweep; 1: the four reused slots before the outside sweep
 void launch_tree_init(const TreeBatch& b, uint32_t nseq, uint32_t max_n, bool contra, int what,
                       hipStream_t st);
@@ -150,21 +158,17 @@ void launch_tree_init(const TreeBatch& b, uint32_t nseq, uint32_t max_n, bool co
 // workgroups write (nd_count = 0: none).  Needs the far ring of a banded workspace (ring != 0).
 void launch_tree_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
                         int64_t tpc_knob, bool two, uint32_t thr, bool use_far, uint32_t nd0,
-                        uint32_t nd_count, hipStream_t st);
+                        uint32_t nd_count, const TreePolicy& pol, hipStream_t st);
 void launch_tree_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
                          int64_t tpc_knob, bool two, uint32_t thr, bool use_far, uint32_t nd0,
-                         uint32_t nd_count, hipStream_t st);
+                         uint32_t nd_count, const TreePolicy& pol, hipStream_t st);
 // Mid-field of the cubic products for the cells of diagonals [dlo, dhi] (one band), threshold thr:
 // inside (outside = false) sums_multibranch, outside probs_multibranch and the Q1 x R part of L_e
 void launch_tree_mid(const TreeBatch& b, bool outside, uint32_t dlo, uint32_t dhi, uint32_t thr,
-                     uint32_t max_n, uint32_t nseq, hipStream_t st);
-void tree_mid_policy(int64_t wgs);  // workgroups per k_tree_mid launch
-void tree_ahead_policy(int64_t waves);  // waves up to which the ahead role takes one wave per cell
+                     uint32_t max_n, uint32_t nseq, const TreePolicy& pol, hipStream_t st);
 // sums_external's first row and last column of a banded sweep, diagonals [dlo, dhi] (in order)
 void launch_tree_ext(const TreeBatch& b, bool contra, uint32_t dlo, uint32_t dhi, uint32_t max_n,
                      uint32_t nseq, hipStream_t st);
-// threads-per-cell policy: waves a launch may hold, sums up to which one wave per cell is taken
-void tree_policy(int64_t waves, int64_t short_terms);
 // per-cell statics (hairpin / multibranch-close / accessible scores, 2-loop sides), once per group
 void launch_tree_static(const TreeBatch& b, bool contra, uint32_t nseq, uint32_t max_n, hipStream_t st);
 void launch_tree_finalize(const TreeBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st);

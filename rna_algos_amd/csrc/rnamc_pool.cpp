@@ -34,7 +34,7 @@ namespace {
 
 double sweep_cost(uint64_t n) {
   const double x = static_cast<double>(n);
-  return 3.25e-12 * (x * (x * x - 1.0) / 6.0) + 6.6e-10 * x * x;
+  return RNAMC_COST_S_PER_CELL_K * (x * (x * x - 1.0) / 6.0) + RNAMC_COST_S_PER_N2 * x * x;
 }
 
 // shard of every sequence: bands of the cost-sorted order (longest first, stable) with equal
@@ -77,6 +77,12 @@ void plan(uint32_t n_seqs, const uint64_t* offsets, uint32_t n_shards, uint32_t*
 }  // namespace
 
 extern "C" {
+
+int rnamc_sweep_cost(uint32_t count, const uint64_t* lengths, double* cost_s) {
+  if (count && (!lengths || !cost_s)) return RNAMC_ERR_INVALID_ARG;
+  for (uint32_t x = 0; x < count; x++) cost_s[x] = sweep_cost(lengths[x]);
+  return RNAMC_OK;
+}
 
 int rnamc_shard_plan(uint32_t n_seqs, const uint64_t* offsets, uint32_t n_shards,
                      uint32_t* shard_of_seq) {

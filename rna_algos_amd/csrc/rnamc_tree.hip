@@ -1765,7 +1765,7 @@ void launch_tree_init(const TreeBatch& b, uint32_t nseq, uint32_t max_n, bool co
 
 #define RNAMC_TREE_LAUNCH(K, C, T, U)                                                            \
   do {                                                                                            \
-    const uint32_t gx_ = tree_grid<T>(cells, nd0, nd_count, max_n, nseq, ah);                           \
+    const uint32_t gx_ = tree_grid<T>(cells, nd0, nd_count, max_n, nseq, pol, ah);                      \
     hipLaunchKernelGGL((K<C, T, U>), dim3(gx_, nseq, 1), dim3(T < 256 ? 256 : T), 0, st, b, d,    \
                        two ? 0 : 1, thr, ah);                                                     \
   } while (0)
@@ -1778,33 +1778,25 @@ void launch_tree_init(const TreeBatch& b, uint32_t nseq, uint32_t max_n, bool co
 // have taken twice).
 // grid of a sweep launch: the workgroups of its own cells, then one wave per row of the next
 // launch's first diagonal (the ahead role)
-static uint64_t g_tree_ahead_waves = 1u << 30;  // (rnamc_ctx_set "tree_ahead_waves")
 template <int T>
 static uint32_t tree_grid(uint32_t cells, uint32_t nd0, uint32_t nd_count, uint32_t max_n, uint32_t nseq_,
-                          Ahead& ah) {
+                          const TreePolicy& pol, Ahead& ah) {
   constexpr uint32_t per = T < 256 ? 256 / T : 1, block = T < 256 ? 256 : T;
   ah.main_blocks = (cells + per - 1) / per;
   ah.nd0 = nd0;
   ah.nd_count = (nd_count && nd0 < max_n) ? nd_count : 0u;
   uint32_t rows = ah.nd_count ? max_n - nd0 : 0u;
   // one ahead wave per cell while the launch's waves still fit the chip at once
-  if (ah.nd_count == 2u && static_cast<uint64_t>(cells + 2u * rows) * nseq_ <= g_tree_ahead_waves) {
+  if (ah.nd_count == 2u && static_cast<uint64_t>(cells + 2u * rows) * nseq_ <= pol.ahead_waves) {
     ah.flags |= 2u;
     rows *= 2u;
   }
   return ah.main_blocks + (rows + block / 64 - 1) / (block / 64);
 }
-static uint64_t g_tree_waves = 5120;  // (rnamc_ctx_set "tree_waves" / "tree_short": tuning)
-static uint32_t g_tree_short = 256;
-void tree_ahead_policy(int64_t waves) { g_tree_ahead_waves = waves > 0 ? static_cast<uint64_t>(waves) : 0u; }
-void tree_policy(int64_t waves, int64_t short_terms) {
-  if (waves > 0) g_tree_waves = static_cast<uint64_t>(waves);
-  if (short_terms > 0) g_tree_short = static_cast<uint32_t>(short_terms);
-}
-static int tree_tpc(uint64_t cells, uint32_t terms, int64_t knob) {
+static int tree_tpc(uint64_t cells, uint32_t terms, int64_t knob, const TreePolicy& pol) {
   if (knob == 64 || knob == 128 || knob == 256 || knob == 1024) return static_cast<int>(knob);
-  const uint64_t kWaves = g_tree_waves;
-  if (terms <= g_tree_short || cells * 2u > kWaves) return 64;
+  const uint64_t kWaves = pol.waves;
+  if (terms <= pol.short_terms || cells * 2u > kWaves) return 64;
   if (cells * 4u > kWaves) return 128;
   if (terms <= 2048u || cells * 16u > kWaves) return 256;
   return 1024;
@@ -1821,12 +1813,12 @@ void launch_tree_static(const TreeBatch& b, bool contra, uint32_t nseq, uint32_t
 
 void launch_tree_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
                         int64_t tpc_knob, bool two, uint32_t thr, bool use_far, uint32_t nd0,
-                        uint32_t nd_count, hipStream_t st) {
+                        uint32_t nd_count, const TreePolicy& pol, hipStream_t st) {
   const uint32_t cells = max_n - d;
   Ahead ah{use_far ? 1u : 0u, 0u, 0u, 0u};
   // (banded: the sums are short whatever d is; what more threads per cell buy is one closing-pair
   // block per wave, so the group is as wide as the chip has room for)
-  const int tpc = tree_tpc(static_cast<uint64_t>(cells) * nseq, thr ? 1024u : d, tpc_knob);
+  const int tpc = tree_tpc(static_cast<uint64_t>(cells) * nseq, thr ? 1024u : d, tpc_knob, pol);
   if (use_far) {  // (one wave per cell pair: what wider groups bought was a block per wave)
     if (contra) RNAMC_TREE_LAUNCH(k_tree_inside2, true, 64, true);
     else RNAMC_TREE_LAUNCH(k_tree_inside2, false, 64, true);
@@ -1845,10 +1837,10 @@ void launch_tree_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t ma
 
 void launch_tree_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq,
                          int64_t tpc_knob, bool two, uint32_t thr, bool use_far, uint32_t nd0,
-                         uint32_t nd_count, hipStream_t st) {
+                         uint32_t nd_count, const TreePolicy& pol, hipStream_t st) {
   const uint32_t cells = max_n - d;
   Ahead ah{use_far ? 1u : 0u, 0u, 0u, 0u};
-  const int tpc = tree_tpc(static_cast<uint64_t>(cells) * nseq, thr ? 1024u : max_n - d, tpc_knob);
+  const int tpc = tree_tpc(static_cast<uint64_t>(cells) * nseq, thr ? 1024u : max_n - d, tpc_knob, pol);
   if (use_far) {
     if (contra) RNAMC_TREE_LAUNCH(k_tree_outside2, true, 64, true);
     else RNAMC_TREE_LAUNCH(k_tree_outside2, false, 64, true);
@@ -1866,16 +1858,12 @@ void launch_tree_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t m
 #undef RNAMC_TREE_LAUNCH
 }
 
-static uint32_t g_tree_mid_wgs = 256;  // workgroups of a k_tree_mid launch (rnamc_ctx_set "tree_mid_wgs")
-void tree_mid_policy(int64_t wgs) {
-  if (wgs > 0) g_tree_mid_wgs = static_cast<uint32_t>(wgs);
-}
 void launch_tree_mid(const TreeBatch& b, bool outside, uint32_t dlo, uint32_t dhi, uint32_t thr,
-                     uint32_t max_n, uint32_t nseq, hipStream_t st) {
+                     uint32_t max_n, uint32_t nseq, const TreePolicy& pol, hipStream_t st) {
   if (dlo >= max_n || dhi < dlo || nseq == 0) return;
   const uint32_t tiles_i = (max_n - dlo + kMidTI - 1) / kMidTI;
   const uint32_t tiles_z = ((dhi - dlo) / kMidTD + 1) * (outside ? 2u : 1u);
-  const uint32_t gx = std::max(1u, std::min(tiles_i * tiles_z, (g_tree_mid_wgs + nseq - 1) / nseq));
+  const uint32_t gx = std::max(1u, std::min(tiles_i * tiles_z, (pol.mid_wgs + nseq - 1) / nseq));
   hipLaunchKernelGGL(k_tree_mid, dim3(gx, nseq, 1), dim3(64 * kMidWaves), 0, st, b, dlo, dhi, thr,
                      outside ? 1 : 0, tiles_i, tiles_z);
 }

@@ -140,9 +140,22 @@ class Context:
 
     def __init__(self, fold_score_sets, device=-1, workspace_bytes=0):
         self._h = C.c_void_p()
+        self._owned = True
         self._key = fold_score_sets.content_key()
         _lib.check(_lib.lib().rnamc_ctx_create(fold_score_sets.ptr, device, workspace_bytes,
                                                C.byref(self._h)))
+
+    @classmethod
+    def of_pool(cls, pool, idx=0):
+        """Context `idx` of a Pool as a Context (owned by the pool: close() leaves it alone)."""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p(_lib.lib().rnamc_pool_ctx(pool._h, idx))
+        if not self._h:
+            raise IndexError(idx)
+        self._owned = False
+        self._key = pool._key
+        self._pool = pool  # keeps the owner alive
+        return self
 
     def sync_params(self, fold_score_sets):
         """Upload the tables again if their contents differ from the ones on the device."""
@@ -153,10 +166,11 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            try:
-                _lib.lib().rnamc_ctx_destroy(self._h)
-            except Exception:  # interpreter shutdown: the binding module is already torn down
-                pass
+            if getattr(self, "_owned", True):
+                try:
+                    _lib.lib().rnamc_ctx_destroy(self._h)
+                except Exception:  # interpreter shutdown: the binding module is already torn down
+                    pass
             self._h = C.c_void_p()
 
     __del__ = close
@@ -320,21 +334,47 @@ def shard_plan(lengths, n_shards):
     return out
 
 
-# ONE device context per process for the module-level functions (workspace and staging
-# buffers are reused across calls).  The reference reads `&FoldScoreSets` on every call, and
-# the set is mutable: the tables are re-uploaded whenever their CONTENT differs from what the
-# context holds — never keyed by object identity, nothing is kept alive per set.
+# ONE pool per process for the module-level functions (workspaces and staging buffers are reused
+# across calls); the single-sequence functions use ITS first context, so a process never holds two
+# contexts on one device.  Which devices: RNAMC_DEVICES="0,2" lists them; under a one-process-per-GPU
+# launch (LOCAL_RANK set: torchrun, bench.py) the rank's own device only — a rank that saw every
+# device would open streams, tables and a workspace on all of them and shard its batch across its
+# peers' GPUs; otherwise every visible device, as the reference's binary takes every core
+# (src/bin/mccaskill_algo.rs:44-48).  The reference reads `&FoldScoreSets` on every call, and the
+# set is mutable: the tables are re-uploaded whenever their CONTENT differs from what the contexts
+# hold — never keyed by object identity, nothing is kept alive per set.
 _ctx = None
+_pool = None
 _ctx_lock = threading.RLock()
+
+
+def default_devices():
+    """None = every visible device (resolved by rnamc_pool_create), else the list to use."""
+    import os
+    if os.environ.get("RNAMC_DEVICES"):
+        return [int(x) for x in os.environ["RNAMC_DEVICES"].split(",") if x.strip() != ""]
+    if os.environ.get("LOCAL_RANK") is not None:
+        return [int(os.environ["LOCAL_RANK"])]
+    return None
+
+
+def _pool_for(fold_score_sets):
+    global _pool
+    with _ctx_lock:
+        if _pool is None:
+            _pool = Pool(fold_score_sets, default_devices())
+        else:
+            _pool.sync_params(fold_score_sets)
+        return _pool
 
 
 def _context_for(fold_score_sets):
     global _ctx
     with _ctx_lock:
+        pool = _pool_for(fold_score_sets)  # (uploads changed tables to every context, this one included)
         if _ctx is None:
-            _ctx = Context(fold_score_sets)
-        else:
-            _ctx.sync_params(fold_score_sets)
+            _ctx = Context.of_pool(pool, 0)
+        _ctx._key = pool._key
         return _ctx
 
 
@@ -362,9 +402,6 @@ def mccaskill_algo(seq, uses_contra_model, allows_short_hairpins, fold_score_set
     return mat.sparse(), FoldScores(materialise)
 
 
-_pool = None
-
-
 def get_fold_sums(seq, fold_score_sets):
     """`get_fold_sums<T>(seq, &mut fold_scores) -> FoldSums<T>` (src/mccaskill_algo.rs:282-378,
     Turner) on the device.  The reference also fills `fold_scores` on the way; here that is
@@ -378,19 +415,10 @@ def get_fold_sums_contra(seq, allows_short_hairpins, fold_score_sets):
     return _context_for(fold_score_sets).fold_sums(seq, True, allows_short_hairpins)
 
 
-def _pool_for(fold_score_sets):
-    global _pool
-    with _ctx_lock:
-        if _pool is None:
-            _pool = Pool(fold_score_sets)  # every visible device
-        else:
-            _pool.sync_params(fold_score_sets)
-        return _pool
-
-
 def mccaskill_algo_batch(seqs, uses_contra_model, allows_short_hairpins, fold_score_sets):
-    """Whole FASTA at once, over every visible GPU (what src/bin/mccaskill_algo.rs:58-93 does on
-    all cores with one pool task per record)."""
+    """Whole FASTA at once, over the process's devices (`default_devices`: every visible GPU unless
+    RNAMC_DEVICES / LOCAL_RANK say otherwise) — what src/bin/mccaskill_algo.rs:58-93 does on all
+    cores with one pool task per record."""
     with _ctx_lock:
         return _pool_for(fold_score_sets).bpp_batch(list(seqs), uses_contra_model,
                                                     allows_short_hairpins)

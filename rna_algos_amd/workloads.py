@@ -47,11 +47,16 @@ def pair_cost(n):
 
 
 def sweep_cost(n):
-    """Measured cost model of one sequence on an MI355X, seconds: the Theta(n^3) folds plus
-    the Theta(n^2 * 496) 2-loop blocks (fit to a 512-sequence group of n ~ 2000 and a
-    4000-sequence group of n = 256..964).  Used to balance shards."""
-    n = np.asarray(n, dtype=np.float64)
-    return 3.25e-12 * pair_cost(n) + 6.6e-10 * n * n
+    """Measured cost model of one sequence on an MI355X, seconds: the Theta(n^3) folds plus the
+    Theta(n^2 * 496) 2-loop blocks (fit to a 512-sequence group of n ~ 2000 and a 4000-sequence
+    group of n = 256..964).  Used to balance shards.  Evaluated by the
+    library (rnamc_sweep_cost; constants RNAMC_COST_* of include/rnamc.h): ONE source for
+    rnamc_shard_plan, bench.py's shards and this function."""
+    from . import _lib
+    a = np.ascontiguousarray(np.atleast_1d(np.asarray(n)), dtype=np.uint64)
+    out = np.empty(a.shape[0], dtype=np.float64)
+    _lib.check(_lib.lib().rnamc_sweep_cost(a.shape[0], a.ctypes.data, out.ctypes.data))
+    return out if np.ndim(n) else float(out[0])
 
 
 def paired_fraction(seq):

@@ -76,6 +76,16 @@ def test_bench_launcher_two_ranks_gloo_dry_run():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["dry_run"] is True
     assert rec["config"]["sequences_all_ranks"] == 300
+    # what a multi-GPU line is judged on (round-3 verdict, item 6): every rank's pass time, its
+    # share of the batch, the cost model's prediction, its golden-check count, the imbalance
+    assert len(rec["per_rank_s"]) == 2 and rec["per_rank_s"] == [0.01, 0.02]
+    assert sum(rec["per_rank_sequences"]) == 300 and min(rec["per_rank_sequences"]) > 0
+    sys.path.insert(0, ROOT)
+    from rna_algos_amd import workloads as W
+    assert sum(rec["per_rank_nt"]) == int(W.batch_lengths(300).sum())
+    assert rec["per_rank_golden_checked"] == [0, 0]
+    assert abs(rec["imbalance"] - 0.02 / 0.015) < 1e-9
+    assert 1.0 <= rec["model_imbalance"] < 1.02  # equal-cost bands under the model
     # --gpus 2 inside a one-rank world: refused, non-zero
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",

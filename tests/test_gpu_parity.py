@@ -431,6 +431,30 @@ def test_fold_sums_match_reference_stage(ctx, params, trnas, contra, short):
     assert_same(mats[0].packed, rb, "bpp after fold_sums on the same context")
 
 
+@pytest.mark.parametrize("contra", [False, True])
+def test_fold_sums_batch_forms_and_guards(ctx, params, contra):
+    """rnamc_fold_sums through the chip-filling batch kernels (latency_mode = 0: a lone sequence
+    would otherwise take the latency forms only — round-3 advisor) equals the oracle's stage bit
+    for bit; n beyond RNAMC_MAX_SEQ_LEN is refused before anything is sized by it; a stats query
+    with no buffer is harmless."""
+    import ctypes as C
+    from rna_algos_amd import _lib
+    seq = np.random.default_rng(77).integers(0, 4, 330).astype(np.uint8)
+    ctx.set("latency_mode", 0)
+    try:
+        got = ctx.fold_sums(seq, contra, False)
+    finally:
+        ctx.set("latency_mode", 1)
+    ref = O.fold_sums(params.ptr, seq, contra, False)
+    for name in O.FOLD_SUMS_FIELDS:
+        assert np.array_equal(got.dense[name].view(np.uint32), ref[name].view(np.uint32)), name
+    tiny = np.zeros(8, dtype=np.uint8)
+    st = _lib.lib().rnamc_fold_sums(ctx._h, tiny.ctypes.data, 70000, int(contra), 0, *([None] * 7))
+    assert st == _lib.ERR_SEQ_TOO_LONG
+    need = C.c_uint64(0)
+    assert _lib.lib().rnamc_ctx_stats(ctx._h, None, 0, C.byref(need)) == 0 and need.value == C.sizeof(_lib.BatchStats)
+
+
 def test_mccaskill_algo_returns_fold_scores(params, trnas):
     """The mirror of the reference entry point returns (bpp map, FoldScores) with the maps
     filled like the reference's (lazily, on first access)."""

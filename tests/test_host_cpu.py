@@ -254,3 +254,26 @@ def test_shard_plan_partitions_and_balances(built):
         assert np.array_equal(shard_plan(small, world), want)
     assert shard_plan([77], 4).tolist() == [0]
     assert shard_plan([], 4).shape == (0,)
+
+
+def test_cost_model_has_one_source(built):
+    """rnamc_shard_plan, bench.py's shards and workloads.sweep_cost evaluate ONE cost model
+    (rnamc_sweep_cost, constants RNAMC_COST_* of include/rnamc.h): equal to the bit with the
+    header's formula on the 10k lengths, and the library's plan equals bench.py's banded shards."""
+    import re
+    import bench
+    from rna_algos_amd import _lib, workloads as W
+    hdr = open(os.path.join(ROOT, "include", "rnamc.h")).read()
+    a = float(re.search(r"#define RNAMC_COST_S_PER_CELL_K\s+(\S+)", hdr).group(1))
+    b = float(re.search(r"#define RNAMC_COST_S_PER_N2\s+(\S+)", hdr).group(1))
+    lens = W.batch_lengths(10000)
+    x = lens.astype(np.float64)
+    assert np.array_equal(W.sweep_cost(lens), a * (x * (x * x - 1.0) / 6.0) + b * x * x)
+    assert W.sweep_cost(1024) == a * (1024.0 * (1024.0 ** 2 - 1.0) / 6.0) + b * 1024.0 ** 2
+    offsets = np.zeros(len(lens) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=offsets[1:])
+    for world in (2, 8):
+        shard_of = np.zeros(len(lens), dtype=np.uint32)
+        _lib.check(_lib.lib().rnamc_shard_plan(len(lens), offsets.ctypes.data, world, shard_of.ctypes.data))
+        for r, idx in enumerate(bench.shard_banded(W.sweep_cost(lens), world)):
+            assert np.all(shard_of[idx] == r)
