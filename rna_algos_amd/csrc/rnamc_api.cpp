@@ -80,10 +80,6 @@ struct rnamc_ctx {
   // workgroups of the previous launch (rnamc_tree.hip, Ahead)
   int64_t tree_ahead = 1;
   TreePolicy tree_pol;  // launch shapes of the tree-order sweep ("tree_waves", "tree_short", ...)
-  // tree mode, banded sweeps: the banded diagonals are swept tree_band_steps() = 8 per launch
-  // (rnamc_tree_band.h: a workgroup owns a trapezoid of the band, its steps are separated by
-  // workgroup barriers); 0: two diagonals per launch everywhere
-  int64_t tree_steps = 1;
   hipStream_t bulk_stream = nullptr;  // k_tree_mid, beside the sweep (lowest priority)
   int64_t tree_debug = 0;  // (RNAMC_DEBUG_KNOBS builds: bit 0 no 2-loops, 1 no products, 2 empty kernels)
   int64_t group_max_seqs = 8192;
@@ -680,39 +676,6 @@ void build_tree_tabs(const rnamc_params& P, TreeTabs& T) {
       T.len[1][p] = (s0 + se) + f.interior_scores_len_cumulative[len - 2u];
     }
   }
-  // the class-ordered list (band launches): specials of each model left out
-  for (int m = 0; m < 2; m++) {
-    auto special = [&](uint32_t a, uint32_t b) {
-      if (m == 0) return (a + b <= 1u) || (a >= 1u && a <= 2u && b >= 1u && b <= 2u);
-      return a <= 1u && b <= 1u;
-    };
-    auto cls_of = [](uint32_t a, uint32_t b) -> uint32_t {
-      if ((a == 0u) != (b == 0u)) return 0u;
-      if (a == 1u || b == 1u) return 1u;
-      if ((a == 2u && b == 3u) || (a == 3u && b == 2u)) return 2u;
-      return 3u;
-    };
-    auto p_of = [](uint32_t a, uint32_t b) -> uint32_t {  // inverse of probe_slot (rnamc_tree.hip)
-      if (a <= 14u) return a * 32u + b;
-      if (a == 15u) return 15u * 32u + b;
-      const uint32_t r = 30u - a;
-      return r * 32u + (31u - r) + b;
-    };
-    const uint32_t first_group[4] = {0u, 2u, 4u, 5u}, groups[4] = {2u, 2u, 1u, 12u};
-    for (uint32_t c = 0; c < 4; c++) {
-      uint32_t at = first_group[c] * 32u;
-      for (uint32_t a = 0; a <= 30u; a++)
-        for (uint32_t b = 0; a + b <= 30u; b++) {
-          if (special(a, b) || cls_of(a, b) != c) continue;
-          if (at >= (first_group[c] + groups[c]) * 32u) continue;  // (never: counts 58, 54 | 56, 2, 375 | 376)
-          T.slot_len[m][at] = T.len[m][p_of(a, b)];
-          T.slot_ab[m][at] = a | (b << 8) | (1u << 16);
-          at++;
-        }
-    }
-    for (uint32_t a = 0; a < 8; a++)
-      for (uint32_t b = 0; b < 8; b++) T.len_ab[m][a][b] = T.len[m][a * 32u + b];
-  }
 }
 
 int ensure_tree_tabs(rnamc_ctx* c, hipStream_t st) {
@@ -939,21 +902,10 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
           if (x >= 3) HIPCHK(hipStreamWaitEvent(st, c->ev_b[x % ering], 0));
         }
         const uint32_t thr = x >= 3 ? (x - 1) * band : 0u;
-        if (thr != 0u && c->tree_steps != 0) {
-          // a band launch: up to 8 diagonals, never across a mid-field band boundary
-          const uint32_t ns = std::min(std::min(tree_band_steps(), gmax - d), (x + 1) * band - d);
-          launch_tree_band(b, contra, false, d, ns, thr, gmax, active(d), st);
-          use_far = false;
-          c->stats.launches_inside++;
-          d += ns;
-          continue;
-        }
         const bool pair = (d % 2u == 0u) && d + 1 < gmax;
         // the next launch's diagonals: their 2-loop blocks' far parts ride in this launch
         const uint32_t nd0 = d + (pair ? 2u : 1u);
-        // (... unless the next launch is a band launch, which forms its blocks itself)
-        const bool next_banded = c->tree_steps != 0 && nd0 / band >= 3u;
-        const uint32_t ndc = (!ahead || nd0 >= gmax || next_banded) ? 0u : ((nd0 % 2u == 0u && nd0 + 1 < gmax) ? 2u : 1u);
+        const uint32_t ndc = (!ahead || nd0 >= gmax) ? 0u : ((nd0 % 2u == 0u && nd0 + 1 < gmax) ? 2u : 1u);
         launch_tree_inside(b, contra, d, gmax, active(d), c->tree_tpc, pair, thr, use_far, nd0, ndc, c->tree_pol, st);
         use_far = ndc != 0u;
         c->stats.launches_inside++;
@@ -990,21 +942,11 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
           if ((x + 2) * band < gmax) HIPCHK(hipStreamWaitEvent(st, c->ev_b[x % ering], 0));
         }
         const uint32_t thr = (x + 2) * band < gmax ? (x + 2) * band : 0u;
-        if (thr != 0u && c->tree_steps != 0) {
-          const uint32_t ns = std::min(std::min(tree_band_steps(), du - x * band + 1u), du - dmin_out + 1u);
-          // (sequences that enter the sweep inside the launch: active at its LOWEST diagonal)
-          launch_tree_band(b, contra, true, du, ns, thr, gmax, active(du + 1u - ns), st);
-          use_far = false;
-          c->stats.launches_outside++;
-          dd -= ns;
-          continue;
-        }
         const bool pair = du % 2u == 1u && du - 1 >= dmin_out;
         const uint32_t lower = pair ? du - 1 : du;
         // the next launch (below): a pair when its top is odd and both diagonals are swept
         uint32_t nd0 = 0, ndc = 0;
-        const bool next_banded = c->tree_steps != 0 && lower >= 1u && ((lower - 1u) / band + 2u) * band < gmax;
-        if (ahead && lower >= dmin_out + 1 && !next_banded) {
+        if (ahead && lower >= dmin_out + 1) {
           const uint32_t top = lower - 1;
           const bool npair = top % 2u == 1u && top - 1 >= dmin_out;
           nd0 = npair ? top - 1 : top;
@@ -1272,8 +1214,6 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
   const std::string k(name);
   if (k == "summation_mode" && (value == 0 || value == 1)) {
     c->summation_mode = value;
-  } else if (k == "tree_steps" && value >= 0) {
-    c->tree_steps = value;
   } else if (k == "tree_waves" && value >= 64) {
     c->tree_pol.waves = static_cast<uint64_t>(value);
   } else if (k == "tree_short" && value >= 1) {

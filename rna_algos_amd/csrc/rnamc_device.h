@@ -101,26 +101,16 @@ enum TreeMat : int {
   T_ACCS = 14, // accessible score (static)                                  row
   T_CS4 = 15,  // float4 per cell, row: the pair as CLOSING pair of a generic 2-loop, by class (static)
   T_IN4 = 19,  // float4 per cell, row: the pair as ENCLOSED pair (static)
-  T_NEAR4 = 23,  // float4 per cell, row: scores of the explicit small 2-loops this pair CLOSES, slots
-                 // 0..3 of Special<>::slot: enclosed pair (i+1,j-1), (i+1,j-2), (i+2,j-1), (i+2,j-2) (static)
-  T_NEAR8 = 27,  // float4 per cell, row: slots 4..6 (Turner: 1x2, 2x1, 2x2; .w unused) (static)
-  T_COUNT = 31
+  T_NEAR4 = 23,  // float4 per cell, row: scores of the pair's three nearest explicit 2-loops,
+                 // enclosed pair (i+1,j-1), (i+1,j-2), (i+2,j-1) (static; .w unused)
+  T_COUNT = 27
 };
 // Length-dependent part of a generic 2-loop score per probe slot (rnamc_tree.hip, probe_slot),
 // derived from rnamc_params on the host (rnamc_api.cpp, build_tree_tabs).  Model index 0 Turner,
 // 1 CONTRAfold.
 struct TreeTabs {
   float len[2][512];
-  // The generic probe slots once more, ORDERED BY CLASS for the band launches (rnamc_tree_band.h):
-  // 17 groups of 32 slots — groups 0,1 class 0 (bulges), 2,3 class 1 (1 x many), 4 class 2 (2 x 3),
-  // 5..16 class 3 — so that a group's class (the plane its gathers read, the component of the
-  // cell's CS4 / IN4 it adds) is uniform over a wave.  slot_ab: a | b << 8 | valid << 16.
-  float slot_len[2][544];
-  uint32_t slot_ab[2][544];
-  float len_ab[2][8][8];  // len of the generic slot (a, b), a, b < 8 (in-band probes of a band launch)
 };
-constexpr int kSlotGroups = 17;
-__host__ __device__ inline uint32_t slot_group_class(uint32_t g) { return g < 2u ? 0u : (g < 4u ? 1u : (g < 5u ? 2u : 3u)); }
 struct TreeSeq {
   uint32_t n, ld;
   uint64_t msz;       // floats per matrix
@@ -176,11 +166,6 @@ void launch_tree_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t m
 // inside (outside = false) sums_multibranch, outside probs_multibranch and the Q1 x R part of L_e
 void launch_tree_mid(const TreeBatch& b, bool outside, uint32_t dlo, uint32_t dhi, uint32_t thr,
                      uint32_t max_n, uint32_t nseq, const TreePolicy& pol, hipStream_t st);
-// Band launch (rnamc_tree_band.h): `nsteps` <= tree_band_steps() anti-diagonals in ONE launch, inside
-// d0 upwards, outside d0 downwards; all in one mid-field band of threshold thr != 0
-uint32_t tree_band_steps();
-void launch_tree_band(const TreeBatch& b, bool contra, bool outside, uint32_t d0, uint32_t nsteps, uint32_t thr,
-                      uint32_t max_n, uint32_t nseq, hipStream_t st);
 // sums_external's first row and last column of a banded sweep, diagonals [dlo, dhi] (in order)
 void launch_tree_ext(const TreeBatch& b, bool contra, uint32_t dlo, uint32_t dhi, uint32_t max_n,
                      uint32_t nseq, hipStream_t st);

@@ -459,16 +459,15 @@ __global__ void __launch_bounds__(256) k_tree_static(TreeBatch b) {
     reinterpret_cast<float4*>(q.m[T_IN4])[o] = in4;
     // the three nearest explicit 2-loops this pair closes (slots (0,0) (0,1) (1,0): kNear), so
     // that the sweep's launches find their scores with the cell's other operands
-    float nr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (uint32_t t = 0; t < Special<CONTRA>::N; t++) {
+    float nr[3] = {0.f, 0.f, 0.f};
+    for (uint32_t t = 0; t < kNear; t++) {
       uint32_t a, bb;
       Special<CONTRA>::slot(t, a, bb);
       if (a + bb + 3u <= d)
         nr[t] = TModel<CONTRA>::twoloop(b, a, bb, si, sj, s[i + 1], s[i + 2], s[j - 1], s[j - 2], s[i + 1 + a],
                                         s[j - 1 - bb], s[j - bb], s[i + a]);
     }
-    reinterpret_cast<float4*>(q.m[T_NEAR4])[o] = make_float4(nr[0], nr[1], nr[2], nr[3]);
-    if (Special<CONTRA>::N > 4) reinterpret_cast<float4*>(q.m[T_NEAR8])[o] = make_float4(nr[4], nr[5], nr[6], 0.f);
+    reinterpret_cast<float4*>(q.m[T_NEAR4])[o] = make_float4(nr[0], nr[1], nr[2], 0.f);
   }
 }
 
@@ -1739,8 +1738,6 @@ __global__ void __launch_bounds__(1024) k_tree_ext(TreeBatch b, uint32_t dlo, ui
   }
 }
 
-#include "rnamc_tree_band.h"
-
 __global__ void __launch_bounds__(256) k_tree_finalize(TreeBatch b) {
   const TreeSeq sd = b.use_one ? b.one : b.seqs[blockIdx.y];
   float* out = b.out + sd.out_off;
@@ -1869,24 +1866,6 @@ void launch_tree_mid(const TreeBatch& b, bool outside, uint32_t dlo, uint32_t dh
   const uint32_t gx = std::max(1u, std::min(tiles_i * tiles_z, (pol.mid_wgs + nseq - 1) / nseq));
   hipLaunchKernelGGL(k_tree_mid, dim3(gx, nseq, 1), dim3(64 * kMidWaves), 0, st, b, dlo, dhi, thr,
                      outside ? 1 : 0, tiles_i, tiles_z);
-}
-
-// One launch for `nsteps` <= 8 anti-diagonals (rnamc_tree_band.h): inside d0, d0+1, ..; outside d0,
-// d0-1, ..  All of them lie in one mid-field band (thr != 0 is theirs).
-uint32_t tree_band_steps() { return kBB; }
-void launch_tree_band(const TreeBatch& b, bool contra, bool outside, uint32_t d0, uint32_t nsteps, uint32_t thr,
-                      uint32_t max_n, uint32_t nseq, hipStream_t st) {
-  if (nseq == 0 || nsteps == 0) return;
-  const uint32_t dfirst = outside ? d0 + 1u - nsteps : d0;  // the diagonal with the most cells
-  if (dfirst >= max_n) return;
-  const uint32_t gx = (max_n - dfirst + kBR - 1) / kBR;
-  if (outside) {
-    if (contra) hipLaunchKernelGGL(k_tree_band_out<true>, dim3(gx, nseq, 1), dim3(1024), 0, st, b, d0, nsteps, thr);
-    else hipLaunchKernelGGL(k_tree_band_out<false>, dim3(gx, nseq, 1), dim3(1024), 0, st, b, d0, nsteps, thr);
-  } else {
-    if (contra) hipLaunchKernelGGL(k_tree_band_in<true>, dim3(gx, nseq, 1), dim3(1024), 0, st, b, d0, nsteps, thr);
-    else hipLaunchKernelGGL(k_tree_band_in<false>, dim3(gx, nseq, 1), dim3(1024), 0, st, b, d0, nsteps, thr);
-  }
 }
 
 void launch_tree_ext(const TreeBatch& b, bool contra, uint32_t dlo, uint32_t dhi, uint32_t max_n,

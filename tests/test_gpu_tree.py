@@ -41,7 +41,7 @@ def run(ctx, seqs, contra, short, mode, **knobs):
     finally:
         ctx.set("summation_mode", 0)
         for k in knobs:
-            ctx.set(k, {"tree_two": 1, "tree_tpc": 0, "tree_band": 64, "tree_ahead": 1, "tree_steps": 1}[k])
+            ctx.set(k, {"tree_two": 1, "tree_tpc": 0, "tree_band": 64, "tree_ahead": 1}[k])
 
 
 def deviation(a, b):
@@ -228,34 +228,6 @@ def test_tree_banded_mid_field(ctx, params, contra, short):
     # deterministic run to run (fixed merge order of the eight waves of a tile)
     m2, z2 = run(ctx, [seqs[15]], contra, short, 1, tree_band=32)
     assert np.array_equal(np.asarray(m2[0].packed), np.asarray(m[0].packed))
-
-
-@pytest.mark.parametrize("contra,short", VARIANTS)
-def test_tree_band_launches(ctx, params, contra, short):
-    """Band launches (rnamc_tree_band.h, tree_steps = 1: eight banded anti-diagonals per launch, a
-    workgroup per trapezoid, the in-band cells through LDS) against the two-diagonals-per-launch
-    sweep of the same mode (tree_steps = 0): the same terms in another grouping — equal to f32
-    rounding, key sets equal; lone sequences and a ragged group; lengths around the first banded
-    diagonal (3 * 64), band ends, a partial last band launch; and against the exact f64 evaluation."""
-    lens = (193, 194, 199, 200, 201, 208, 255, 256, 257, 263, 264, 265, 300, 383, 410, 640)
-    seqs = [O.splitmix_seq(n, 17 * n + 3) for n in lens]
-    base, zbase = run(ctx, seqs, contra, short, 1, tree_steps=0)
-    tol = lambda n: 2 * (2e-5 + 2e-7 * n)
-    m, z = run(ctx, seqs, contra, short, 1, tree_steps=1)
-    for s, a, b0, za, zb in zip(seqs, m, base, z, zbase):
-        same, dp = deviation(a.packed, b0.packed)
-        assert same and dp <= tol(len(s)), (len(s), dp)
-        assert abs(float(za) - float(zb)) <= 3e-6 * max(1.0, abs(float(zb))), len(s)
-    for x in (0, 4, 8, 12, 15):  # alone: other launch shapes (no ragged prefix, other grid)
-        m1, z1 = run(ctx, [seqs[x]], contra, short, 1, tree_steps=1)
-        same, dp = deviation(m1[0].packed, base[x].packed)
-        assert same and dp <= tol(len(seqs[x])), (len(seqs[x]), dp)
-        m2, z2 = run(ctx, [seqs[x]], contra, short, 1, tree_steps=1)
-        assert np.array_equal(np.asarray(m2[0].packed), np.asarray(m1[0].packed)) and z1[0] == z2[0], "not deterministic"
-    for x in (7, 14):
-        xb, xz = O.exact_bpp(params.ptr, seqs[x], contra, short)
-        same, dt = deviation(m[x].packed, xb)
-        assert same and dt <= 2e-5 + 2e-7 * len(seqs[x]) and abs(float(z[x]) - xz) <= 2e-5 + 3e-6 * abs(xz)
 
 
 def test_tree_ragged_batch_and_lone_calls(ctx, params):
