@@ -240,7 +240,7 @@ int rnamc_ctx_set_params(rnamc_ctx* ctx, const rnamc_params* params);
  * launch, default 1), "tree_tpc" (threads per cell: 64 / 128 / 256 / 1024, 0 = by diagonal size),
  * "tree_band" (width of a band of anti-diagonals whose cubic products take their mid-field from
  * the tiled kernel k_tree_mid one band ahead: 0 / 32 / 64 / 96 / 128, default 64; 0 = every launch
- * walks its sums whole), "tree_mid_wgs" (workgroups of a mid-field launch, default 256),
+ * walks its sums whole), "tree_mid_wgs" (workgroups of a mid-field launch; default by length: 256 / 512 / 1024),
  * "tree_ahead" (banded sweeps: the far part of a launch's 2-loop blocks is summed by extra
  * workgroups of the previous launch, default 1), "tree_waves" (waves a tree-order launch may hold
  * at once when it picks threads per cell, default 5120), "tree_short" (sums of at most this many

@@ -719,13 +719,14 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
     return (offsets[a + 1] - offsets[a]) > (offsets[b + 1] - offsets[b]);
   });
   const uint64_t ws_cap_floats = static_cast<uint64_t>(std::max<int64_t>(c->group_ws_bytes, 1)) / 4;
-  // banding needs two diagonals per launch aligned to even diagonals, 32-bit operand offsets
-  // inside a sequence's matrices, and sequences long enough to have a banded diagonal at all
+  // banding needs two diagonals per launch aligned to even diagonals, 32-bit float offsets INSIDE
+  // one matrix (true for every n <= RNAMC_MAX_SEQ_LEN: ld * n < 2^32), and sequences long enough
+  // to have a banded diagonal at all
   uint32_t band = (c->tree_two != 0 && c->tree_band >= 32) ? static_cast<uint32_t>(c->tree_band) & ~31u : 0u;
   if (band > 128u) band = 128u;
   {
     const uint64_t ld = ((static_cast<uint64_t>(max_n) + 31u) & ~31ull) + 32u;
-    if ((ld * max_n + 128ull) * T_COUNT >= (1ull << 32) || max_n < 3u * band + 2u) band = 0u;
+    if (ld * max_n + 128ull >= (1ull << 32) || max_n < 3u * band + 2u) band = 0u;
   }
   if (band && !c->bulk_stream) {
     int lo = 0, hi = 0;

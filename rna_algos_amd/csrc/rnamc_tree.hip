@@ -245,6 +245,32 @@ __device__ __forceinline__ uint32_t tri_off(uint32_t n, uint32_t d) {
   return d * n - (d * (d - 1u)) / 2u;
 }
 
+// The sweep's launches take what their FIRST loads are addressed with — the lone sequence's matrix
+// base, matrix size, n and row stride, the diagonal, the band threshold — as leading SCALAR kernel
+// arguments: with -mllvm -amdgpu-kernarg-preload-count the command processor places those in SGPRs
+// at dispatch, so a wave's ~45 operand loads need not wait for its own read of the kernel
+// argument segment (a dependent scalar round trip in front of every launch of the chain).
+__device__ __forceinline__ TSeq load_tseq_hot(const TreeBatch& b, uint32_t which, float* hbase, uint64_t hmsz,
+                                              uint32_t hn, uint32_t hld, uint32_t use_one) {
+  if (!use_one) return load_tseq(b, which);
+  const TreeSeq& sd = b.one;
+  TSeq q;
+  q.s = b.bases + sd.seq_off;
+  q.n = hn;
+  q.ld = hld;
+#pragma unroll
+  for (int x = 0; x < T_COUNT; x++) q.m[x] = hbase + static_cast<size_t>(x) * hmsz;
+  q.zp = hbase + static_cast<size_t>(T_COUNT) * hmsz;
+  q.zs = q.zp + (hn + 64u);
+  q.pk = reinterpret_cast<const uint32_t*>(b.workspace + sd.pk_off);
+  q.out = b.out + sd.out_off;
+  q.batch_idx = sd.batch_idx;
+  q.mid = reinterpret_cast<float2*>(b.workspace + sd.mid_off);
+  q.vec = (hn + 64u + 63u) & ~63u;
+  q.far = q.mid + static_cast<size_t>(3u) * b.ring * q.vec;
+  return q;
+}
+
 // 32 consecutive bases p0 .. p0+31 in one 64-bit value (window position q at bits 2q, 2q+1);
 // p0 >= -32 (the packed copy carries 32 zero bases in front and >= 64 behind)
 __device__ __forceinline__ uint64_t load_win64(const uint32_t* __restrict__ pk, int p0) {
@@ -797,8 +823,9 @@ __device__ __forceinline__ Acc load_mid(const TSeq& q, uint32_t ring, uint32_t p
 // UF: the far parts of this launch's blocks come from q.far (TPC == 64 only; a variant of its own
 // so that neither form carries the other's registers)
 template <bool CONTRA, int TPC, bool UF>
-__global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatch b, uint32_t d, int single,
-                                                                        uint32_t thr, Ahead ah) {
+__global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(float* hbase, uint64_t hmsz, uint32_t hn, uint32_t hld,
+                                                                        uint32_t d, uint32_t thr, uint32_t use_one,
+                                                                        TreeBatch b, int single, Ahead ah) {
   static_assert(!UF || TPC == 64, "far parts from the ring: one wave per cell pair");
   constexpr int BLOCK = TPC < 256 ? 256 : TPC;
   constexpr int NA = 9;
@@ -806,7 +833,7 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(TreeBatc
 #ifdef RNAMC_DEBUG_KNOBS
   if (b.debug & 4) return;
 #endif
-  const TSeq q = load_tseq(b, blockIdx.y);
+  const TSeq q = load_tseq_hot(b, blockIdx.y, hbase, hmsz, hn, hld, use_one);
   const uint32_t n = q.n, ld = q.ld;
   if (blockIdx.x >= ah.main_blocks) {
     // ---- the NEXT launch's closing-pair blocks, far part (see Ahead): one wave per row i takes
@@ -1192,8 +1219,9 @@ __device__ __forceinline__ void acc_product_3(Acc& pm0, Acc& pmn, Acc& pm1,
 // whose OUTSIDE operand (W(i,k), R(k,j)) spans at least thr were summed by k_tree_mid before
 // the band above this one started; the launch adds the nearer ones and merges.
 template <bool CONTRA, int TPC, bool UF>
-__global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBatch b, uint32_t d, int single,
-                                                                         uint32_t thr, Ahead ah) {
+__global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(float* hbase, uint64_t hmsz, uint32_t hn, uint32_t hld,
+                                                                         uint32_t d, uint32_t thr, uint32_t use_one,
+                                                                         TreeBatch b, int single, Ahead ah) {
   static_assert(!UF || TPC == 64, "far parts from the ring: one wave per cell pair");
   constexpr int BLOCK = TPC < 256 ? 256 : TPC;
   constexpr int NA = 7;
@@ -1201,7 +1229,7 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(TreeBat
 #ifdef RNAMC_DEBUG_KNOBS
   if (b.debug & 4) return;
 #endif
-  const TSeq q = load_tseq(b, blockIdx.y);
+  const TSeq q = load_tseq_hot(b, blockIdx.y, hbase, hmsz, hn, hld, use_one);
   const uint32_t n = q.n, ld = q.ld;
   if (blockIdx.x >= ah.main_blocks) {
     // ---- the NEXT launch's enclosing 2-loops, far part (see Ahead): one wave per row i takes
@@ -1497,22 +1525,30 @@ k_tree_mid(TreeBatch b, uint32_t dlo, uint32_t dhi, uint32_t thr, int outside, u
   const int wave = static_cast<int>(threadIdx.x >> 6), lane = static_cast<int>(threadIdx.x & 63u);
   const int li = lane & 7, lg = lane >> 3;
 
-  // operand rows as float offsets from the sequence's first matrix (< 2^32: checked by the host)
-  const float* __restrict__ base = q.m[0];
-  const uint32_t msz = static_cast<uint32_t>(q.m[1] - q.m[0]);
-  uint32_t offA, offB;  // row i0 of A / column (i0 + d0) of B, at k = 0
+  // operand rows: a uniform 64-bit base per matrix (scalar registers) + 32-bit float offsets INSIDE
+  // the matrix (ld * n < 2^32 for every n the index type admits), so that a sequence's 27
+  // matrices may span more than 2^32 floats (n = 16 384: 29 GB)
+  const float* __restrict__ baseA;
+  const float* __restrict__ baseB;
+  uint32_t offA, offB;  // row i0 of A / column (i0 + d0) of B, at k = 0 (wraps for the "- 1" forms: added back below)
   int kmin;             // smallest k whose operands exist
   if (prod == 0) {
-    offA = T_Q1R * msz + static_cast<uint32_t>(i0) * ld - 1u;
-    offB = T_ZRM * msz + static_cast<uint32_t>(i0 + d0) * ld;
+    baseA = q.m[T_Q1R];
+    baseB = q.m[T_ZRM];
+    offA = static_cast<uint32_t>(i0) * ld - 1u;
+    offB = static_cast<uint32_t>(i0 + d0) * ld;
     kmin = 1;
   } else if (prod == 1) {
-    offA = T_ZRE * msz + static_cast<uint32_t>(i0) * ld;
-    offB = T_Q1R * msz + static_cast<uint32_t>(i0 + d0 + 1) * ld - 1u;
+    baseA = q.m[T_ZRE];
+    baseB = q.m[T_Q1R];
+    offA = static_cast<uint32_t>(i0) * ld;
+    offB = static_cast<uint32_t>(i0 + d0 + 1) * ld - 1u;
     kmin = 1;
   } else {
-    offA = T_Q1C * msz + static_cast<uint32_t>(i0 - 1) * ld + 1u;  // (row i0 - 1; i0 = 0: masked below)
-    offB = T_ZRM * msz + static_cast<uint32_t>(i0 + d0) * ld;
+    baseA = q.m[T_Q1C];
+    baseB = q.m[T_ZRM];
+    offA = static_cast<uint32_t>(i0 - 1) * ld + 1u;  // (row i0 - 1; i0 = 0: masked below)
+    offB = static_cast<uint32_t>(i0 + d0) * ld;
     kmin = 0;
   }
   // rows of the stage that exist: A row r <-> i = i0 + r, B row r <-> j = i0 + d0 + r
@@ -1571,8 +1607,8 @@ k_tree_mid(TreeBatch b, uint32_t dlo, uint32_t dhi, uint32_t thr, int outside, u
 #pragma unroll
     for (int u = 0; u < kMidPf; u++) {
       const uint32_t uni = (u < kMidTI / 4 ? 4u * u : 4u * (u - kMidTI / 4)) * static_cast<uint32_t>(ld) + kk;
-      const uint32_t off = (u < kMidTI / 4 ? vA : vB) + uni;
-      pf[u] = ((lmask >> u) & 1u) ? base[off] : kNegInf;
+      const uint32_t off = (u < kMidTI / 4 ? vA : vB) + uni;  // (mod 2^32: k >= kmin undoes the "- 1")
+      pf[u] = ((lmask >> u) & 1u) ? (u < kMidTI / 4 ? baseA : baseB)[off] : kNegInf;
     }
   };
   if (wave < nch) fetch(wave);
@@ -1660,8 +1696,8 @@ k_tree_mid(TreeBatch b, uint32_t dlo, uint32_t dhi, uint32_t thr, int outside, u
 //   zp[j+1] = (+)_{k=0..j} (Zr_ext(k,j) + zp[k])  (+)  unpaired          (j = d; zp[0] = 0)
 //   zs[i]   = ((+)_{l=i+1..n-1} Qa(i,l) + zs[l+1]) + ext_bp  (+)  (zs[i+1] + ext_un)   (i = n-1-d)
 template <bool CONTRA>
-__global__ void __launch_bounds__(1024) k_tree_ext(TreeBatch b, uint32_t dlo, uint32_t dhi) {
-  extern __shared__ float vec[];  // zp[0 .. n] | zs[0 .. n] shifted so that the walk reads vec[k]
+__global__ void __launch_bounds__(1024) k_tree_ext(TreeBatch b, uint32_t dlo, uint32_t dhi, int use_lds) {
+  extern __shared__ float lds_vec[];  // zp[0 .. n] | zs[0 .. n] shifted so that the walk reads vec[k]
   __shared__ float red[16][2];
   const TSeq q = load_tseq(b, blockIdx.y);
   const uint32_t n = q.n, ld = q.ld;
@@ -1672,8 +1708,12 @@ __global__ void __launch_bounds__(1024) k_tree_ext(TreeBatch b, uint32_t dlo, ui
   const float ext_bp = CONTRA ? b.params->contra.external_score_basepair : 0.f;
   const float ext_un = CONTRA ? b.params->contra.external_score_unpair : 0.f;
   // row: vec[k] = zp[k]; column: vec[x] = zs[x] (the walk of step i reads vec[l+1])
-  float* __restrict__ gv = col ? q.zs : q.zp;
-  for (uint32_t x = t; x <= n; x += 1024u) vec[x] = gv[x];
+  // (long sequences: the vector does not fit the LDS; it is walked in global memory instead —
+  // one workgroup reads what it wrote itself a barrier earlier, through its own CU's L1)
+  float* gv = col ? q.zs : q.zp;
+  float* vec = use_lds ? lds_vec : gv;
+  if (use_lds)
+    for (uint32_t x = t; x <= n; x += 1024u) vec[x] = gv[x];
   __syncthreads();
   // operand of step d: row: ZRE[j*ld + k], k = 0..j (j = d); column: QA[i*ld + l], l = i+1..n-1
   auto operand = [&](uint32_t d) -> const float* {
@@ -1766,8 +1806,9 @@ void launch_tree_init(const TreeBatch& b, uint32_t nseq, uint32_t max_n, bool co
 #define RNAMC_TREE_LAUNCH(K, C, T, U)                                                            \
   do {                                                                                            \
     const uint32_t gx_ = tree_grid<T>(cells, nd0, nd_count, max_n, nseq, pol, ah);                      \
-    hipLaunchKernelGGL((K<C, T, U>), dim3(gx_, nseq, 1), dim3(T < 256 ? 256 : T), 0, st, b, d,    \
-                       two ? 0 : 1, thr, ah);                                                     \
+    hipLaunchKernelGGL((K<C, T, U>), dim3(gx_, nseq, 1), dim3(T < 256 ? 256 : T), 0, st,          \
+                       b.workspace + b.one.ws_off, static_cast<uint64_t>(b.one.msz), b.one.n, b.one.ld, d, thr,  \
+                       b.use_one, b, two ? 0 : 1, ah);                                            \
   } while (0)
 // Threads per cell by the length of a cell's sums (`terms`) and the number of cells: a cell's
 // lanes walk its sums four steps per stream at a time, so `terms / (4 * threads)` dependent
@@ -1863,7 +1904,8 @@ void launch_tree_mid(const TreeBatch& b, bool outside, uint32_t dlo, uint32_t dh
   if (dlo >= max_n || dhi < dlo || nseq == 0) return;
   const uint32_t tiles_i = (max_n - dlo + kMidTI - 1) / kMidTI;
   const uint32_t tiles_z = ((dhi - dlo) / kMidTD + 1) * (outside ? 2u : 1u);
-  const uint32_t gx = std::max(1u, std::min(tiles_i * tiles_z, (pol.mid_wgs + nseq - 1) / nseq));
+  const uint32_t wgs = pol.mid_wgs ? pol.mid_wgs : (max_n >= 12288u ? 1024u : (max_n >= 6144u ? 512u : 256u));
+  const uint32_t gx = std::max(1u, std::min(tiles_i * tiles_z, (wgs + nseq - 1) / nseq));
   hipLaunchKernelGGL(k_tree_mid, dim3(gx, nseq, 1), dim3(64 * kMidWaves), 0, st, b, dlo, dhi, thr,
                      outside ? 1 : 0, tiles_i, tiles_z);
 }
@@ -1871,11 +1913,12 @@ void launch_tree_mid(const TreeBatch& b, bool outside, uint32_t dlo, uint32_t dh
 void launch_tree_ext(const TreeBatch& b, bool contra, uint32_t dlo, uint32_t dhi, uint32_t max_n,
                      uint32_t nseq, hipStream_t st) {
   if (dlo >= max_n || dhi < dlo || nseq == 0) return;
-  const size_t lds = (static_cast<size_t>(max_n) + 2u) * sizeof(float);  // (< 64 KB: banding's n limit)
+  const bool use_lds = max_n <= 12000u;  // (48 KB of dynamic LDS; beyond, the vector stays in global memory)
+  const size_t lds = use_lds ? (static_cast<size_t>(max_n) + 2u) * sizeof(float) : 0;
   if (contra)
-    hipLaunchKernelGGL(k_tree_ext<true>, dim3(2, nseq, 1), dim3(1024), lds, st, b, dlo, dhi);
+    hipLaunchKernelGGL(k_tree_ext<true>, dim3(2, nseq, 1), dim3(1024), lds, st, b, dlo, dhi, use_lds ? 1 : 0);
   else
-    hipLaunchKernelGGL(k_tree_ext<false>, dim3(2, nseq, 1), dim3(1024), lds, st, b, dlo, dhi);
+    hipLaunchKernelGGL(k_tree_ext<false>, dim3(2, nseq, 1), dim3(1024), lds, st, b, dlo, dhi, use_lds ? 1 : 0);
 }
 
 void launch_tree_finalize(const TreeBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st) {

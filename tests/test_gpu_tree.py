@@ -135,8 +135,13 @@ EXACT_FIXTURES = ["exact_n1024_seed1024_contra", "exact_n1024_seed1024_turner", 
 def test_tree_vs_committed_exact_f64(ctx, params, name):
     """The tree-order mode pinned AT SCALE (round-3 verdict, missing 4): n = 1024 both models, n = 2048
     and n = 4096 Turner against committed f64 evaluations of the recurrences — many bands of the
-    banded sweep, ring wrap-arounds at depth, every kernel of the mode.  Bounds as at n <= 410
-    (test_tree_vs_exact_f64): |dp| <= 2e-5 + 2e-7 n, |d ln Z| <= 2e-5 + 3e-6 |ln Z|, key set equal."""
+    banded sweep, ring wrap-arounds at depth, every kernel of the mode.  Key set equal; up to
+    n = 1024 the bounds of test_tree_vs_exact_f64 (|dp| <= 2e-5 + 2e-7 n, |d ln Z| <= 2e-5 + 3e-6 |ln Z|).
+    Beyond, what bounds an f32 log-domain DP is the resolution of its values, not the summation
+    order: ln Z = 1431 (n = 2048) / 2957 (n = 4096) carry ulps of 1.2e-4 / 2.4e-4, and a probability
+    is the exp of a difference of such values — measured 7.2e-4 / 8.3e-4 at n = 2048; the bound is
+    16 ulps of ln Z for both, and the reference-order result of the same library must sit FURTHER
+    from the exact value (it does, by an order of magnitude: its fold is approximate on top)."""
     import os
     if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", name + ".npz")):
         pytest.skip(f"{name}.npz not generated (python tests/make_golden.py exact|exact4096)")
@@ -152,10 +157,23 @@ def test_tree_vs_committed_exact_f64(ctx, params, name):
     dz = abs(float(z[0]) - float(f["log_partition"][0]))
     print(f"{name}: tree-order vs committed f64: max |dp| = {dp:.3e} over {f['index'].size} pairs, "
           f"|d ln Z| = {dz:.3e} (ln Z = {float(f['log_partition'][0]):.4f})")
-    assert dp <= 2e-5 + 2e-7 * n
-    assert dz <= 2e-5 + 3e-6 * abs(float(f["log_partition"][0]))
-    # sum over the sampled pairs as a second, aggregate check (no cancellation hides a bias)
-    assert abs(float(p[f["index"]].astype(np.float64).sum()) - float(f["prob"].sum())) <= 1e-5 * f["index"].size ** 0.5 + 1e-4
+    xz = float(f["log_partition"][0])
+    ulp = float(np.spacing(np.float32(abs(xz))))
+    if n <= 1024:
+        assert dp <= 2e-5 + 2e-7 * n
+        assert dz <= 2e-5 + 3e-6 * abs(xz)
+    else:
+        assert dp <= 16 * ulp and dz <= 16 * ulp, (dp, dz, ulp)
+    mr, zr = run(ctx, [s], contra, False, 0)
+    pr = np.asarray(mr[0].packed)
+    dpr = float(np.max(np.abs(pr[f["index"]].astype(np.float64) - f["prob"])))
+    dzr = abs(float(zr[0]) - xz)
+    print(f"{name}: reference-order vs committed f64: max |dp| = {dpr:.3e}, |d ln Z| = {dzr:.3e}  (ulp of ln Z {ulp:.2e})")
+    assert dp < dpr and dz < dzr, "tree-order mode should sit closer to the exact value than the reference fold"
+    # sum over the sampled pairs as a second, aggregate check: what may be systematic is the error of
+    # ln Z itself (every log-probability carries it with the same sign), nothing beyond it
+    bias = abs(float(p[f["index"]].astype(np.float64).sum()) - float(f["prob"].sum()))
+    assert bias <= (dz + 4 * ulp) * float(f["prob"].sum()) + 1e-5 * f["index"].size ** 0.5 + 1e-4, bias
 
 
 def test_tree_n4096_turner(ctx, params):
@@ -176,6 +194,88 @@ def test_tree_n4096_turner(ctx, params):
     d[d < 0] = 0
     rows = d.sum(axis=1) + d.sum(axis=0)
     assert rows.max() <= 1.0 + 5e-3
+
+
+def test_tree_n16384_banded_and_oom(params):
+    """n = 16 384 (a sequence's 27 dense matrices: 29 GB, more than 2^32 floats): the banded sweep
+    addresses its operands by a 64-bit base per matrix + 32-bit offsets inside it, sums_external's
+    vectors are walked in global memory (they do not fit the LDS) — key set = every canonical pair of
+    span >= 5 (Turner: static), probabilities in range, row sums <= 1, the banded sweep equal to the
+    unbanded one to rounding, and several times faster.  n = 65 535 (what T = u16 admits) would
+    need 464 GB: refused with RNAMC_ERR_OOM, and the context works afterwards."""
+    import time
+    import torch
+    from rna_algos_amd import _lib
+    from rna_algos_amd.mccaskill_algo import Context
+    n = 16384
+    s = O.splitmix_seq(n, n)
+    dev = torch.device("cuda:0")
+    b = torch.from_numpy(np.ascontiguousarray(s)).to(dev)
+    off = np.array([0, n], dtype=np.uint64)
+    oo = np.array([0, n * (n + 1) // 2], dtype=np.uint64)
+    z = torch.empty(1, dtype=torch.float32, device=dev)
+    c = Context(params, device=0)
+    c.set("summation_mode", 1)
+    outs, secs = {}, {}
+    try:
+        for band in (64, 0):
+            c.set("tree_band", band)
+            o = torch.empty(n * (n + 1) // 2, dtype=torch.float32, device=dev)
+            for rep in range(2):  # (the first call allocates the 29-GB workspace)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                c.bpp_batch_device(1, b.data_ptr(), off, False, False, o.data_ptr(), oo, z.data_ptr(), 0)
+                torch.cuda.synchronize()
+                secs[band] = time.perf_counter() - t0
+            outs[band] = (o, float(z[0]))
+        print(f"tree-order n={n}: banded {secs[64] * 1e3:.0f} ms, unbanded {secs[0] * 1e3:.0f} ms, ln Z {outs[64][1]:.3f}")
+        ob, zb = outs[64]
+        ou, zu = outs[0]
+        kb, ku = ob >= -0.5, ou >= -0.5
+        assert bool(torch.equal(kb, ku))
+        assert float((ob[kb] - ou[kb]).abs().max()) <= 2 * (2e-5 + 2e-7 * n)
+        assert abs(zb - zu) <= 3e-6 * abs(zu)
+        assert secs[64] < 0.6 * secs[0]
+        # key set: canonical pairs of span >= 5, diagonal-major
+        st = torch.from_numpy(s.astype(np.int64)).to(dev)
+        chk = 0
+        for d in (0, 3, 4, 5, 100, 4095, 8192, 12000, n - 2, n - 1):
+            seg = ob[d * n - d * (d - 1) // 2: d * n - d * (d - 1) // 2 + n - d]
+            t = st[:n - d] + st[d:]
+            want = ((t == 3) | (t == 5)) & (d >= 4)
+            assert bool(torch.equal(seg >= -0.5, want)), d
+            chk += int(want.sum())
+        assert chk > 0
+        pres = ob[kb]
+        # (ln Z = 11 612: one f32 ulp is 9.8e-4, and a probability is the exp of a difference of such
+        # values — the reference's own bound 1.001 does not survive f32 at this length in any order)
+        ulp = float(np.spacing(np.float32(abs(zb))))
+        assert float(pres.min()) >= -0.001 and float(pres.max()) < 1.0 + 16 * ulp
+        # row sums on a slice of rows (dense unpacking of 16384^2 would take 1 GB: do it by diagonals)
+        rows = torch.zeros(n, dtype=torch.float64, device=dev)
+        p0 = torch.clamp(ob, min=0).double()
+        for d in range(4, n):
+            base = d * n - d * (d - 1) // 2
+            seg = p0[base:base + n - d]
+            rows[:n - d] += seg
+            rows[d:] += seg
+        assert float(rows.max()) <= 1.0 + 32 * ulp
+        # 464 GB of workspace: refused, nothing broken
+        del ob, ou, outs, p0
+        torch.cuda.empty_cache()
+        big = 65535
+        sb = torch.zeros(big, dtype=torch.uint8, device=dev)
+        obig = torch.empty(8, dtype=torch.float32, device=dev)  # (never written: the call fails before any launch)
+        offb = np.array([0, big], dtype=np.uint64)
+        oob = np.array([0, big * (big + 1) // 2], dtype=np.uint64)
+        with pytest.raises(_lib.RnamcError) as ei:
+            c.bpp_batch_device(1, sb.data_ptr(), offb, False, False, obig.data_ptr(), oob, z.data_ptr(), 0)
+        assert ei.value.status == _lib.ERR_OOM
+        m, zz = c.bpp_batch([O.splitmix_seq(300, 3)], False, False)
+        assert np.isfinite(float(zz[0]))
+    finally:
+        c.set("summation_mode", 0)
+        c.close()
 
 
 @pytest.mark.parametrize("contra,short", VARIANTS)
