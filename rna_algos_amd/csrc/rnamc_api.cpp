@@ -31,6 +31,7 @@ using namespace rnamc;
     hipError_t _e = (expr);                                                                \
     if (_e != hipSuccess) {                                                                \
       set_last_error(std::string(#expr) + ": " + hipGetErrorString(_e));                   \
+      (void)hipGetLastError(); /* reported: a later call must not find it again */         \
       return (_e == hipErrorOutOfMemory) ? RNAMC_ERR_OOM : RNAMC_ERR_HIP;                  \
     }                                                                                      \
   } while (0)
