@@ -121,7 +121,8 @@ def pmc_traffic_per_launch(kernel, total_T, launches, contra=False):
     prescribes), scaled from that pass's workload to this one by sum n(n^2-1)/6.  None when the
     profile is absent.  The newest round's file wins."""
     names = (("r03_traffic_batch1000_contra.json",) if contra else
-             ("r03_traffic_batch1000.json", "r02_traffic_batch1000.json", "r01_traffic_batch1000.json"))
+             ("r04_traffic_batch1000.json", "r03_traffic_batch1000.json", "r02_traffic_batch1000.json",
+              "r01_traffic_batch1000.json"))
     for name in names:
         path = os.path.join(ROOT, "profiles", name)
         try:
