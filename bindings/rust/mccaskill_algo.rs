@@ -121,8 +121,18 @@ fn with_pool<R>(fold_score_sets: &FoldScoreSets, f: impl FnOnce(*mut RnamcPool) 
       }
       None => {
         let mut pool = std::ptr::null_mut();
-        // n_devices = 0: one context per visible GPU
-        check(unsafe { rnamc_pool_create(p, std::ptr::null(), 0, 0, &mut pool) }, "rnamc_pool_create");
+        // Which devices: RNAMC_DEVICES="0,2" lists them; under a one-process-per-GPU launch
+        // (LOCAL_RANK set) the rank's own device only — a rank that saw every device would open
+        // streams, tables and a workspace on all of them and shard its batch across its peers'
+        // GPUs; otherwise n_devices = 0: one context per visible GPU (the reference's binary
+        // takes every core: src/bin/mccaskill_algo.rs:44-48)
+        let devices: Vec<c_int> = match (std::env::var("RNAMC_DEVICES"), std::env::var("LOCAL_RANK")) {
+          (Ok(v), _) => v.split(',').filter_map(|x| x.trim().parse::<c_int>().ok()).collect(),
+          (_, Ok(r)) => r.trim().parse::<c_int>().map(|d| vec![d]).unwrap_or_default(),
+          _ => Vec::new(),
+        };
+        let dev_ptr = if devices.is_empty() { std::ptr::null() } else { devices.as_ptr() };
+        check(unsafe { rnamc_pool_create(p, dev_ptr, devices.len() as u32, 0, &mut pool) }, "rnamc_pool_create");
         // RNA_ALGOS_SUMMATION_MODE=1 opts in to the tree-order sums (about 10x faster on a lone
         // long sequence; NOT bit-comparable with the reference CPU path: include/rnamc.h,
         // rnamc_ctx_set).  The default, 0, is the reference's own summation order.
@@ -276,7 +286,8 @@ fn unpack_probs<T: HashIndex>(packed: &[f32], n: usize) -> SparseProbMat<T> {
   basepair_probs
 }
 
-// The whole FASTA in one call, sharded over every visible GPU: what
+// The whole FASTA in one call, sharded over the process's GPUs (every visible one unless
+// RNAMC_DEVICES / LOCAL_RANK say otherwise: with_pool): what
 // src/bin/mccaskill_algo.rs:58-93 and src/bin/centroid_fold.rs:119-132 do with one pool task
 // per record on all cores.  Called from that pool instead, every per-sequence call would
 // serialise on the pool and run as a latency-bound group of one on one device.  Returns the
