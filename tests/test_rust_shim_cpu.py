@@ -178,8 +178,10 @@ def test_shim_keeps_reference_semantics():
     code = re.sub(r"//[^\n]*", "", src)
     assert "OnceLock" not in code
     assert "content_key(fold_score_sets)" in code and "rnamc_pool_set_params" in code
-    # the batch entry drives EVERY visible device (n_devices = 0), not the current one alone
-    assert "rnamc_bpp_batch_multi" in code and re.search(r"rnamc_pool_create\(p,\s*std::ptr::null\(\),\s*0,", code)
+    # the batch entry drives a POOL: every visible device by default (null list, n_devices = 0), the
+    # rank's own device under a one-process-per-GPU launch (LOCAL_RANK), or the RNAMC_DEVICES list
+    assert "rnamc_bpp_batch_multi" in code and re.search(r"rnamc_pool_create\(p,\s*dev_ptr,\s*devices\.len\(\) as u32,", code)
+    assert "std::ptr::null()" in code and '"LOCAL_RANK"' in code and '"RNAMC_DEVICES"' in code
     assert 'cfg!(feature = "no-fold-scores")' in code and 'feature = "fold-scores"' not in code
     assert "panic!()" not in code and "rnamc_last_error" in code
     assert "pub fn mccaskill_algo_batch<T>" in code
