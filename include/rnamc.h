@@ -245,7 +245,7 @@ int rnamc_ctx_set_params(rnamc_ctx* ctx, const rnamc_params* params);
  * workgroups of the previous launch, default 1), "tree_waves" (waves a tree-order launch may hold
  * at once when it picks threads per cell, default 5120), "tree_short" (sums of at most this many
  * terms take one wave per cell, default 256), "tree_ahead_waves" (waves up to which the ahead role
- * takes one wave per cell instead of one per row, default 2^30).  Every knob is per context. */
+ * takes one wave per cell instead of one per row, default 16384).  Every knob is per context. */
 int rnamc_ctx_set(rnamc_ctx* ctx, const char* name, int64_t value);
 
 /* mccaskill_algo over a batch (src/mccaskill_algo.rs:247-280 for each record, as

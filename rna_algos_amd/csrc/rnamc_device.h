@@ -144,7 +144,8 @@ struct TreeBatch {
 struct TreePolicy {
   uint64_t waves = 5120;            // waves a launch may hold at once (5 per SIMD at ~88 VGPRs)
   uint32_t short_terms = 256;       // sums up to this many terms take one wave per cell
-  uint64_t ahead_waves = 1u << 30;  // waves up to which the ahead role takes one wave per CELL
+  uint64_t ahead_waves = 16384;    // waves up to which the ahead role takes one wave per CELL (a lone sequence;
+                                    // beyond — batches — one per row: 8 % faster there, profiles/r04_tree_on_batches.txt)
   uint32_t mid_wgs = 0;             // workgroups of a k_tree_mid launch; 0: by the longest sequence (256 below
                                     // 6 144 nt, 512 below 12 288, 1 024 beyond: from ~8 000 nt on the mid-field
                                     // products, not the launch chain, set the sweep's time: profiles/r04_tree_long.txt)

@@ -705,6 +705,90 @@ __device__ __forceinline__ void outer_far(const TreeBatch& b, const TSeq& q, Acc
 }
 
 // ----------------------------------------------------------------------------
+// The uniform operands of a cell pair in ONE vector gather.  A launch of the banded sweep needs ~60
+// scalars per cell pair (statics, the neighbours' sums, ring entries).  As scalar loads behind
+// `cond ? sload(..) : default` the compiler emitted them as ~14 conditional s_load / s_waitcnt pairs
+// in SEQUENCE — 4.3 us of a launch's ~11.7 (tree_debug 8 against 4, round 4) — because a scalar
+// load cannot be predicated.  Here lane x of the wave loads operand x: a descriptor per lane
+// (constant table: which matrix, which neighbour cell, which condition, which default), one
+// `global_load_dword` for all of them, `v_readlane` hands each to the scalar code.  One round trip,
+// and the near-slot gathers and the product streams are issued right behind it.
+//   kind 0: row-major matrix, cell (i + a, j + b)          1: float4 per cell, row-major, component c
+//        2: column-major matrix, cell (i + b, j + a)        3: row-major, cell (i + a, i + b)
+//        4: far ring, diagonal d + a, row i + b, comp c     5..7: mid ring of product kind - 5, diagonal d + a, row i + b, comp c
+//   cond bits: 1 has1, 2 d >= 1, 4 d >= 2, 8 CONTRAfold only, 16 banded (thr != 0), 32 i + b >= 0 (b < 0), 64 j + a < n
+//   dflt: 0 -inf, 1 zero, 2 kEmpty (the max of an empty accumulator)
+constexpr uint32_t opd(uint32_t kind, uint32_t mat, int a, int bb, uint32_t comp, uint32_t cond, uint32_t dflt) {
+  return kind | (mat << 3) | (static_cast<uint32_t>(a + 2) << 8) | (static_cast<uint32_t>(bb + 4) << 11) | (comp << 15) |
+         (cond << 17) | (dflt << 24);
+}
+constexpr uint32_t kOpNone = 7u | (31u << 3);
+struct OpCtx {
+  float* hbase;     // first matrix of the sequence
+  uint64_t hmsz;
+  const float2* far;
+  const float2* mid;
+  uint32_t i, j, d, n, ld, vec, ring;
+  bool has1, contra, banded;
+};
+__device__ __forceinline__ float gather_operand(uint32_t ds, const OpCtx& c) {
+  const uint32_t kind = ds & 7u, mat = (ds >> 3) & 31u, comp = (ds >> 15) & 3u, cond = (ds >> 17) & 127u,
+                 dflt = (ds >> 24) & 3u;
+  const int a = static_cast<int>((ds >> 8) & 7u) - 2, bb = static_cast<int>((ds >> 11) & 15u) - 4;
+  bool ok = ds != kOpNone;
+  ok = ok && (!(cond & 1u) || c.has1) && (!(cond & 2u) || c.d >= 1u) && (!(cond & 4u) || c.d >= 2u) &&
+       (!(cond & 8u) || c.contra) && (!(cond & 16u) || c.banded) &&
+       (!(cond & 32u) || static_cast<int>(c.i) + bb >= 0) && (!(cond & 64u) || c.j + static_cast<uint32_t>(a) < c.n);
+  const float* p = c.hbase;
+  if (kind <= 3u) {
+    size_t off;
+    if (kind == 2u) off = static_cast<size_t>(static_cast<int64_t>(c.j) + a) * c.ld + static_cast<size_t>(static_cast<int64_t>(c.i) + bb);
+    else if (kind == 3u) off = static_cast<size_t>(static_cast<int64_t>(c.i) + a) * c.ld + static_cast<size_t>(static_cast<int64_t>(c.i) + bb);
+    else off = static_cast<size_t>(static_cast<int64_t>(c.i) + a) * c.ld + static_cast<size_t>(static_cast<int64_t>(c.j) + bb);
+    if (kind == 1u) off = 4u * off + comp;
+    p = c.hbase + static_cast<size_t>(mat) * c.hmsz + off;
+  } else if (kind == 4u) {
+    p = reinterpret_cast<const float*>(c.far + static_cast<size_t>((c.d + static_cast<uint32_t>(a)) & 3u) * c.vec +
+                                       static_cast<size_t>(static_cast<int64_t>(c.i) + bb)) + comp;
+  } else {
+    const uint32_t ring = max(c.ring, 1u);
+    p = reinterpret_cast<const float*>(c.mid + (static_cast<size_t>(kind - 5u) * c.ring + (c.d + static_cast<uint32_t>(a)) % ring) * c.vec +
+                                       static_cast<size_t>(static_cast<int64_t>(c.i) + bb)) + comp;
+  }
+  const float v = ok ? *p : 0.f;
+  return ok ? v : (dflt == 0u ? kNegInf : (dflt == 1u ? 0.f : kEmpty));
+}
+__device__ __forceinline__ float* hbase_of(const TSeq& q) { return q.m[0]; }
+__device__ __forceinline__ float lane_value(float v, int lane) {
+  return __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(__float_as_uint(v)), lane)));
+}
+// inside sweep, cells (i,j), (i,j+1), neighbour (i+1,j+1)
+enum InOp : int {
+  IO_MBC0, IO_MBC1, IO_MBCN, IO_HP0, IO_HP1, IO_HPN, IO_ACCS0, IO_ACCS1, IO_ACCSN,
+  IO_CS0, IO_IN0 = IO_CS0 + 4, IO_CS1 = IO_IN0 + 4, IO_IN1 = IO_CS1 + 4, IO_CSN = IO_IN1 + 4,
+  IO_QM0 = IO_CSN + 4, IO_QM1, IO_QMN, IO_ZRE_P, IO_ZRM_P, IO_U_N0, IO_ZRE_PN, IO_ZRM_PN, IO_U_NN, IO_Q1II_A, IO_Q1II_B,
+  IO_FAR0, IO_FARN = IO_FAR0 + 2, IO_FAR1 = IO_FARN + 2, IO_MID0 = IO_FAR1 + 2, IO_MID1 = IO_MID0 + 2, IO_COUNT = IO_MID1 + 2
+};
+static_assert(IO_COUNT <= 64, "one lane per operand");
+__constant__ uint32_t kInOps[64] = {
+    opd(0, T_MBC, 0, 0, 0, 0, 0), opd(0, T_MBC, 0, 1, 0, 1, 0), opd(0, T_MBC, 1, 1, 0, 1, 0),
+    opd(0, T_HP, 0, 0, 0, 0, 0), opd(0, T_HP, 0, 1, 0, 1, 0), opd(0, T_HP, 1, 1, 0, 1, 0),
+    opd(0, T_ACCS, 0, 0, 0, 0, 1), opd(0, T_ACCS, 0, 1, 0, 1, 1), opd(0, T_ACCS, 1, 1, 0, 1, 1),
+    opd(1, T_CS4, 0, 0, 0, 0, 1), opd(1, T_CS4, 0, 0, 1, 0, 1), opd(1, T_CS4, 0, 0, 2, 0, 1), opd(1, T_CS4, 0, 0, 3, 0, 1),
+    opd(1, T_IN4, 0, 0, 0, 0, 1), opd(1, T_IN4, 0, 0, 1, 0, 1), opd(1, T_IN4, 0, 0, 2, 0, 1), opd(1, T_IN4, 0, 0, 3, 0, 1),
+    opd(1, T_CS4, 0, 1, 0, 1, 1), opd(1, T_CS4, 0, 1, 1, 1, 1), opd(1, T_CS4, 0, 1, 2, 1, 1), opd(1, T_CS4, 0, 1, 3, 1, 1),
+    opd(1, T_IN4, 0, 1, 0, 1, 1), opd(1, T_IN4, 0, 1, 1, 1, 1), opd(1, T_IN4, 0, 1, 2, 1, 1), opd(1, T_IN4, 0, 1, 3, 1, 1),
+    opd(1, T_CS4, 1, 1, 0, 1, 1), opd(1, T_CS4, 1, 1, 1, 1, 1), opd(1, T_CS4, 1, 1, 2, 1, 1), opd(1, T_CS4, 1, 1, 3, 1, 1),
+    opd(0, T_QM, 1, -1, 0, 4, 0), opd(0, T_QM, 1, 0, 0, 1 | 2, 0), opd(0, T_QM, 2, 0, 0, 1 | 4, 0),
+    opd(2, T_ZRE, -1, 0, 0, 0, 0), opd(2, T_ZRM, -1, 0, 0, 8, 0), opd(2, T_U, 0, 1, 0, 0, 0),
+    opd(2, T_ZRE, 0, 1, 0, 1, 0), opd(2, T_ZRM, 0, 1, 0, 1 | 8, 0), opd(2, T_U, 1, 2, 0, 1, 0),
+    opd(3, T_Q1R, 0, 0, 0, 1 | 4, 0), opd(2, T_ZRM, 0, 1, 0, 1 | 4, 0),
+    opd(4, 0, 0, 0, 0, 0, 2), opd(4, 0, 0, 0, 1, 0, 1), opd(4, 0, 0, 1, 0, 1, 2), opd(4, 0, 0, 1, 1, 1, 1),
+    opd(4, 0, 1, 0, 0, 1, 2), opd(4, 0, 1, 0, 1, 1, 1),
+    opd(5, 0, 0, 0, 0, 16, 2), opd(5, 0, 0, 0, 1, 16, 1), opd(5, 0, 1, 0, 0, 1 | 16, 2), opd(5, 0, 1, 0, 1, 1 | 16, 1),
+    kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone};
+
+// ----------------------------------------------------------------------------
 // Two diagonals per launch.  The sweep's cost is its NUMBER of dependent launches and the
 // dependent round trips inside each, so one group of TPC threads takes the cells (i, j) and
 // (i, j+1) of diagonals d and d+1 (`single`: the cell (i,j) alone).  What diagonal d+1 needs of
@@ -899,23 +983,12 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(float* h
              do1 = uf ? w0 : (TPC == 64 || wv == (TPC == 128 ? 0u : 2u));
   const uint32_t lane = t & 63u;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  // every uniform operand a wave needs, one round trip (scalar unit)
-  const float mbc0 = w0 ? sload(q.m[T_MBC] + row_i + j) : kNegInf;
-  const float mbc1 = (has1 && (w0 || do1)) ? sload(q.m[T_MBC] + row_i + j1) : kNegInf;
-  const float mbcn = (has1 && (w0 || don)) ? sload(q.m[T_MBC] + row_i + ld + j1) : kNegInf;
-  const float hp0 = w0 ? sload(q.m[T_HP] + row_i + j) : kNegInf;
-  const float hp1 = (has1 && do1) ? sload(q.m[T_HP] + row_i + j1) : kNegInf;
-  const float hpn = (has1 && don) ? sload(q.m[T_HP] + row_i + ld + j1) : kNegInf;
-  const float accs0 = w0 ? sload(q.m[T_ACCS] + row_i + j) : 0.f;
-  const float accs1 = (has1 && w0) ? sload(q.m[T_ACCS] + row_i + j1) : 0.f;
-  const float accsn = (has1 && w0) ? sload(q.m[T_ACCS] + row_i + ld + j1) : 0.f;
-  const float4 cs0 = w0 ? sload4(cs4m + row_i + j) : zero4, in0 = w0 ? sload4(in4m + row_i + j) : zero4;
-  const float4 cs1 = (has1 && do1) ? sload4(cs4m + row_i + j1) : zero4;
-  const float4 in1 = (has1 && w0) ? sload4(in4m + row_i + j1) : zero4;
-  const float4 csn = (has1 && don) ? sload4(cs4m + row_i + ld + j1) : zero4;
-  const float qm0 = (w0 && d >= 2) ? sload(q.m[T_QM] + row_i + ld + (j - 1)) : kNegInf;      // Qm(i+1, j-1)
-  const float qm1 = (has1 && do1 && d >= 1) ? sload(q.m[T_QM] + row_i + ld + j) : kNegInf;   // Qm(i+1, j)
-  const float qmn = (has1 && don && d >= 2) ? sload(q.m[T_QM] + row_i + 2 * static_cast<size_t>(ld) + j) : kNegInf;  // Qm(i+2, j)
+  // every uniform operand of the cell pair: one vector gather in the banded sweep's launches (uf:
+  // gather_operand above), scalar loads in the other variants
+  float mbc0 = kNegInf, mbc1 = kNegInf, mbcn = kNegInf, hp0 = kNegInf, hp1 = kNegInf, hpn = kNegInf;
+  float accs0 = 0.f, accs1 = 0.f, accsn = 0.f;
+  float4 cs0 = zero4, in0 = zero4, cs1 = zero4, in1 = zero4, csn = zero4;
+  float qm0 = kNegInf, qm1 = kNegInf, qmn = kNegInf;
   float zr_e_prev = kNegInf, zr_m_prev = kNegInf, zr_e_prevn = kNegInf, zr_m_prevn = kNegInf;
   float u_next0 = kNegInf, u_nextn = kNegInf;  // U(i+1, j), U(i+2, j+1)
   // (banded sweeps: sums_external's row 0 and column n-1 are k_tree_ext's, a band behind)
@@ -923,24 +996,82 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(float* h
   const bool zs0 = !ext_side && j == n - 1, zs1 = !ext_side && has1 && j1 == n - 1;  // which cell sits in column n-1
   const bool row0 = !ext_side && i == 0;
   float zs_a = 0.f, zs_last = 0.f, zp1 = 0.f, q1_ii = kNegInf;
-  if (w0) {
-    if (j >= 1) {
-      zr_e_prev = sload(q.m[T_ZRE] + col_j - ld + i);
-      if (CONTRA) zr_m_prev = sload(q.m[T_ZRM] + col_j - ld + i);
+  Acc far0 = acc_empty(), farn = acc_empty(), far1 = acc_empty(), mid0 = acc_empty(), mid1 = acc_empty();
+  float nqb = kNegInf, nsc = 0.f;  // (uf) lane 3c + s: sums_close of the pair near slot s of cell c encloses, its score
+  bool ngeo = false;
+  if constexpr (uf) {
+    const OpCtx oc{hbase_of(q), static_cast<uint64_t>(q.m[1] - q.m[0]), q.far, q.mid, i, j, d, n, ld, q.vec, b.ring,
+                   has1, CONTRA, thr != 0u};
+    const float ov = gather_operand(kInOps[lane], oc);
+    // (issued right behind the gather, before anything waits for it: the near slots' sums_close and
+    // scores — slot s of cell c in lane 3c + s — are gathers of their own; whether the cell may pair
+    // at all is applied to the VALUE below)
+    {
+      const uint32_t c = lane / 3u, sl = lane - 3u * c;
+      const uint32_t ci = c == 1u ? i + 1u : i, cj = c == 0u ? j : j1;
+      uint32_t sa, sb;
+      Special<CONTRA>::slot(sl < kNear ? sl : 0u, sa, sb);
+      ngeo = lane < 9u && (c == 0u || has1) && sa + sb + 3u <= cj - ci;
+      if (ngeo) {
+        nqb = q.m[T_QB][static_cast<size_t>(ci + 1u + sa) * ld + (cj - 1u - sb)];
+        nsc = q.m[T_NEAR4][4u * (static_cast<size_t>(ci) * ld + cj) + sl];
+      }
     }
-    u_next0 = sload(q.m[T_U] + col_j + i + 1);  // (i+1 == n: the column's pad, -inf)
-    if (has1) {
-      zr_e_prevn = sload(q.m[T_ZRE] + col_j + i + 1);  // Zr_ext(i+1, j)
-      if (CONTRA) zr_m_prevn = sload(q.m[T_ZRM] + col_j + i + 1);
-      u_nextn = sload(q.m[T_U] + col_j + ld + i + 2);
+    auto OP = [&](int x) { return lane_value(ov, x); };
+    mbc0 = OP(IO_MBC0), mbc1 = OP(IO_MBC1), mbcn = OP(IO_MBCN);
+    hp0 = OP(IO_HP0), hp1 = OP(IO_HP1), hpn = OP(IO_HPN);
+    accs0 = OP(IO_ACCS0), accs1 = OP(IO_ACCS1), accsn = OP(IO_ACCSN);
+    cs0 = make_float4(OP(IO_CS0), OP(IO_CS0 + 1), OP(IO_CS0 + 2), OP(IO_CS0 + 3));
+    in0 = make_float4(OP(IO_IN0), OP(IO_IN0 + 1), OP(IO_IN0 + 2), OP(IO_IN0 + 3));
+    cs1 = make_float4(OP(IO_CS1), OP(IO_CS1 + 1), OP(IO_CS1 + 2), OP(IO_CS1 + 3));
+    in1 = make_float4(OP(IO_IN1), OP(IO_IN1 + 1), OP(IO_IN1 + 2), OP(IO_IN1 + 3));
+    csn = make_float4(OP(IO_CSN), OP(IO_CSN + 1), OP(IO_CSN + 2), OP(IO_CSN + 3));
+    qm0 = OP(IO_QM0), qm1 = OP(IO_QM1), qmn = OP(IO_QMN);
+    zr_e_prev = OP(IO_ZRE_P), zr_m_prev = OP(IO_ZRM_P), u_next0 = OP(IO_U_N0);
+    zr_e_prevn = OP(IO_ZRE_PN), zr_m_prevn = OP(IO_ZRM_PN), u_nextn = OP(IO_U_NN);
+    q1_ii = (has1 && d >= 2u) ? OP(IO_Q1II_A) + OP(IO_Q1II_B) : kNegInf;
+    far0 = Acc{OP(IO_FAR0), OP(IO_FAR0 + 1)};
+    farn = Acc{OP(IO_FARN), OP(IO_FARN + 1)};
+    far1 = Acc{OP(IO_FAR1), OP(IO_FAR1 + 1)};
+    mid0 = Acc{OP(IO_MID0), OP(IO_MID0 + 1)};
+    mid1 = Acc{OP(IO_MID1), OP(IO_MID1 + 1)};
+  } else {
+    mbc0 = w0 ? sload(q.m[T_MBC] + row_i + j) : kNegInf;
+    mbc1 = (has1 && (w0 || do1)) ? sload(q.m[T_MBC] + row_i + j1) : kNegInf;
+    mbcn = (has1 && (w0 || don)) ? sload(q.m[T_MBC] + row_i + ld + j1) : kNegInf;
+    hp0 = w0 ? sload(q.m[T_HP] + row_i + j) : kNegInf;
+    hp1 = (has1 && do1) ? sload(q.m[T_HP] + row_i + j1) : kNegInf;
+    hpn = (has1 && don) ? sload(q.m[T_HP] + row_i + ld + j1) : kNegInf;
+    accs0 = w0 ? sload(q.m[T_ACCS] + row_i + j) : 0.f;
+    accs1 = (has1 && w0) ? sload(q.m[T_ACCS] + row_i + j1) : 0.f;
+    accsn = (has1 && w0) ? sload(q.m[T_ACCS] + row_i + ld + j1) : 0.f;
+    cs0 = w0 ? sload4(cs4m + row_i + j) : zero4;
+    in0 = w0 ? sload4(in4m + row_i + j) : zero4;
+    cs1 = (has1 && do1) ? sload4(cs4m + row_i + j1) : zero4;
+    in1 = (has1 && w0) ? sload4(in4m + row_i + j1) : zero4;
+    csn = (has1 && don) ? sload4(cs4m + row_i + ld + j1) : zero4;
+    qm0 = (w0 && d >= 2) ? sload(q.m[T_QM] + row_i + ld + (j - 1)) : kNegInf;      // Qm(i+1, j-1)
+    qm1 = (has1 && do1 && d >= 1) ? sload(q.m[T_QM] + row_i + ld + j) : kNegInf;   // Qm(i+1, j)
+    qmn = (has1 && don && d >= 2) ? sload(q.m[T_QM] + row_i + 2 * static_cast<size_t>(ld) + j) : kNegInf;  // Qm(i+2, j)
+    if (w0) {
+      if (j >= 1) {
+        zr_e_prev = sload(q.m[T_ZRE] + col_j - ld + i);
+        if (CONTRA) zr_m_prev = sload(q.m[T_ZRM] + col_j - ld + i);
+      }
+      u_next0 = sload(q.m[T_U] + col_j + i + 1);  // (i+1 == n: the column's pad, -inf)
+      if (has1) {
+        zr_e_prevn = sload(q.m[T_ZRE] + col_j + i + 1);  // Zr_ext(i+1, j)
+        if (CONTRA) zr_m_prevn = sload(q.m[T_ZRM] + col_j + i + 1);
+        u_nextn = sload(q.m[T_U] + col_j + ld + i + 2);
+      }
+      if (!ext_side) {
+        zs_a = zs0 ? sload(q.zs + i + 1) : (zs1 ? sload(q.zs + i + 2) : 0.f);  // Z(i+1,n-1) | Z(i+2,n-1)
+        zs_last = zs1 ? sload(q.zs + j + 1) : 0.f;                              // Z(n-1,n-1)
+        zp1 = (i == 0 && has1) ? sload(q.zp + 1) : 0.f;                         // Z(0,0)
+      }
+      // the k = i+1 term of sums_multibranch(i,j) (left out of the two-cell product below)
+      if (has1 && d >= 2) q1_ii = sload(q.m[T_Q1R] + row_i + i) + sload(q.m[T_ZRM] + col_j + i + 1);
     }
-    if (!ext_side) {
-      zs_a = zs0 ? sload(q.zs + i + 1) : (zs1 ? sload(q.zs + i + 2) : 0.f);  // Z(i+1,n-1) | Z(i+2,n-1)
-      zs_last = zs1 ? sload(q.zs + j + 1) : 0.f;                              // Z(n-1,n-1)
-      zp1 = (i == 0 && has1) ? sload(q.zp + 1) : 0.f;                         // Z(0,0)
-    }
-    // the k = i+1 term of sums_multibranch(i,j) (left out of the two-cell product below)
-    if (has1 && d >= 2) q1_ii = sload(q.m[T_Q1R] + row_i + i) + sload(q.m[T_ZRM] + col_j + i + 1);
   }
   const bool act0 = mbc0 > kNegInf, act1 = mbc1 > kNegInf, actn = mbcn > kNegInf;
 #ifdef RNAMC_DEBUG_KNOBS
@@ -958,35 +1089,13 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(float* h
   for (int x = 0; x < NA; x++) acc[x] = acc_empty();
   // [0] [1] [2] closing-pair blocks of (i,j), (i+1,j+1), (i,j+1): one wave each
   float nx = kNegInf;  // (uf) lane 3c + s: near slot s of cell c
-  Acc far0 = acc_empty(), farn = acc_empty(), far1 = acc_empty();
   if constexpr (uf) {
-    if (w0) {
-      // Near part: the explicit small loops with a + b <= 1 (inner pairs of the last three
-      // diagonals) — slot s of cell c in lane 3c + s, all nine at once; the far parts were summed
-      // by the previous launch's ahead blocks
-      far0 = load_far(q, d, i);
-      if (has1) {
-        farn = load_far(q, d, i + 1u);  // (the neighbour sits on this diagonal)
-        far1 = load_far(q, d + 1u, i);
-      }
-      const float4* __restrict__ nr4 = reinterpret_cast<const float4*>(q.m[T_NEAR4]);
-      const float4 nr0 = sload4(nr4 + row_i + j);
-      const float4 nrn = has1 ? sload4(nr4 + row_i + ld + j1) : zero4;
-      const float4 nr1 = has1 ? sload4(nr4 + row_i + j1) : zero4;
-      const uint32_t c = lane / 3u, sl = lane - 3u * c;
-      const bool mine = lane < 9u && (c == 0u ? act0 : (c == 1u ? actn : act1));
-      if (mine) {
-        const uint32_t ci = c == 1u ? i + 1u : i, cj = c == 0u ? j : j1;
-        uint32_t a, bb;
-        Special<CONTRA>::slot(sl, a, bb);
-        if (a + bb + 3u <= cj - ci) {
-          const uint32_t k = ci + 1u + a, l = cj - 1u - bb;
-          const float x = q.m[T_QB][static_cast<size_t>(k) * ld + l];
-          const float sc = c == 0u ? pick(nr0, sl) : (c == 1u ? pick(nrn, sl) : pick(nr1, sl));
-          nx = x + sc;
-        }
-      }
-    }
+    // Near part: the explicit small loops with a + b <= 1 (inner pairs of the last three diagonals) —
+    // slot s of cell c in lane 3c + s, all nine at once, gathered with the operands above; the far
+    // parts were summed by the previous launch's ahead blocks
+    const uint32_t c = lane / 3u;
+    const bool mine = ngeo && (c == 0u ? act0 : (c == 1u ? actn : act1));
+    nx = mine ? nqb + nsc : kNegInf;
   } else {
   if (act0 && do0)
     pair_block<CONTRA, 64>(b, q, acc[0], i, j, lane, hp0, qm0 + mbc0, cs0,
@@ -1035,8 +1144,8 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(float* h
   }
   if (t == 0u) acc_add(acc[3], q1_ii);
   if (thr != 0u && w0) {
-    const Acc m0 = load_mid(q, b.ring, 0u, d, i);
-    const Acc m1 = has1 ? load_mid(q, b.ring, 0u, d + 1u, i) : acc_empty();
+    const Acc m0 = uf ? mid0 : load_mid(q, b.ring, 0u, d, i);
+    const Acc m1 = uf ? mid1 : (has1 ? load_mid(q, b.ring, 0u, d + 1u, i) : acc_empty());
     if (t == 0u) {
       acc_merge(acc[3], m0);
       acc_merge(acc[4], m1);
