@@ -196,12 +196,20 @@ template <int TPC>
 __device__ __forceinline__ void acc_product(Acc& a, const float* __restrict__ A,
                                             const float* __restrict__ B, uint32_t len, uint32_t t) {
   for (uint32_t k = t; k < len; k += 8u * TPC) {
-    float x[8];
+    // (all loads of the chunk first, unconditional — index clamped to the stream's first element,
+    // validity applied to the value — and a scheduling barrier before the arithmetic: left alone the
+    // compiler issued two loads, waited, summed, two loads, waited ...: eight round trips per chunk)
+    float x[8], va[8], vb[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const uint32_t ku = k + static_cast<uint32_t>(u) * TPC;
-      x[u] = ku < len ? A[ku] + B[ku] : kNegInf;
+      const uint32_t kc = ku < len ? ku : 0u;
+      va[u] = A[kc];
+      vb[u] = B[kc];
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; u++) x[u] = (k + static_cast<uint32_t>(u) * TPC < len) ? va[u] + vb[u] : kNegInf;
     acc_add4(a, x[0], x[1], x[2], x[3]);
     acc_add4(a, x[4], x[5], x[6], x[7]);
   }
@@ -716,44 +724,53 @@ __device__ __forceinline__ void outer_far(const TreeBatch& b, const TSeq& q, Acc
 //   kind 0: row-major matrix, cell (i + a, j + b)          1: float4 per cell, row-major, component c
 //        2: column-major matrix, cell (i + b, j + a)        3: row-major, cell (i + a, i + b)
 //        4: far ring, diagonal d + a, row i + b, comp c     5..7: mid ring of product kind - 5, diagonal d + a, row i + b, comp c
-//   cond bits: 1 has1, 2 d >= 1, 4 d >= 2, 8 CONTRAfold only, 16 banded (thr != 0), 32 i + b >= 0 (b < 0), 64 j + a < n
+//        8: sums_external's prefix vector zp[a ? n : i + b]  9: its suffix vector zs[j + b]
+//   cond bits: 1 has1, 2 d >= 1, 4 d >= 2, 8 CONTRAfold only, 16 banded (thr != 0), 32 i + b >= 0, 64 j + 1 < n,
+//              128 j + 2 < n, 256 not has1
 //   dflt: 0 -inf, 1 zero, 2 kEmpty (the max of an empty accumulator)
 constexpr uint32_t opd(uint32_t kind, uint32_t mat, int a, int bb, uint32_t comp, uint32_t cond, uint32_t dflt) {
-  return kind | (mat << 3) | (static_cast<uint32_t>(a + 2) << 8) | (static_cast<uint32_t>(bb + 4) << 11) | (comp << 15) |
-         (cond << 17) | (dflt << 24);
+  return kind | (mat << 4) | (static_cast<uint32_t>(a + 2) << 9) | (static_cast<uint32_t>(bb + 4) << 12) | (comp << 16) |
+         (cond << 18) | (dflt << 27);
 }
-constexpr uint32_t kOpNone = 7u | (31u << 3);
+constexpr uint32_t kOpNone = 15u;
 struct OpCtx {
   float* hbase;     // first matrix of the sequence
   uint64_t hmsz;
   const float2* far;
   const float2* mid;
+  const float* zp;
+  const float* zs;
   uint32_t i, j, d, n, ld, vec, ring;
   bool has1, contra, banded;
 };
 __device__ __forceinline__ float gather_operand(uint32_t ds, const OpCtx& c) {
-  const uint32_t kind = ds & 7u, mat = (ds >> 3) & 31u, comp = (ds >> 15) & 3u, cond = (ds >> 17) & 127u,
-                 dflt = (ds >> 24) & 3u;
-  const int a = static_cast<int>((ds >> 8) & 7u) - 2, bb = static_cast<int>((ds >> 11) & 15u) - 4;
-  bool ok = ds != kOpNone;
+  const uint32_t kind = ds & 15u, mat = (ds >> 4) & 31u, comp = (ds >> 16) & 3u, cond = (ds >> 18) & 511u,
+                 dflt = (ds >> 27) & 3u;
+  const int a = static_cast<int>((ds >> 9) & 7u) - 2, bb = static_cast<int>((ds >> 12) & 15u) - 4;
+  bool ok = kind != kOpNone;
   ok = ok && (!(cond & 1u) || c.has1) && (!(cond & 2u) || c.d >= 1u) && (!(cond & 4u) || c.d >= 2u) &&
-       (!(cond & 8u) || c.contra) && (!(cond & 16u) || c.banded) &&
-       (!(cond & 32u) || static_cast<int>(c.i) + bb >= 0) && (!(cond & 64u) || c.j + static_cast<uint32_t>(a) < c.n);
+       (!(cond & 8u) || c.contra) && (!(cond & 16u) || c.banded) && (!(cond & 32u) || static_cast<int>(c.i) + bb >= 0) &&
+       (!(cond & 64u) || c.j + 1u < c.n) && (!(cond & 128u) || c.j + 2u < c.n) && (!(cond & 256u) || !c.has1);
   const float* p = c.hbase;
+  const int64_t ia = static_cast<int64_t>(c.i) + a, ib = static_cast<int64_t>(c.i) + bb;
   if (kind <= 3u) {
     size_t off;
-    if (kind == 2u) off = static_cast<size_t>(static_cast<int64_t>(c.j) + a) * c.ld + static_cast<size_t>(static_cast<int64_t>(c.i) + bb);
-    else if (kind == 3u) off = static_cast<size_t>(static_cast<int64_t>(c.i) + a) * c.ld + static_cast<size_t>(static_cast<int64_t>(c.i) + bb);
-    else off = static_cast<size_t>(static_cast<int64_t>(c.i) + a) * c.ld + static_cast<size_t>(static_cast<int64_t>(c.j) + bb);
+    if (kind == 2u) off = static_cast<size_t>(static_cast<int64_t>(c.j) + a) * c.ld + static_cast<size_t>(ib);
+    else if (kind == 3u) off = static_cast<size_t>(ia) * c.ld + static_cast<size_t>(ib);
+    else off = static_cast<size_t>(ia) * c.ld + static_cast<size_t>(static_cast<int64_t>(c.j) + bb);
     if (kind == 1u) off = 4u * off + comp;
     p = c.hbase + static_cast<size_t>(mat) * c.hmsz + off;
   } else if (kind == 4u) {
     p = reinterpret_cast<const float*>(c.far + static_cast<size_t>((c.d + static_cast<uint32_t>(a)) & 3u) * c.vec +
-                                       static_cast<size_t>(static_cast<int64_t>(c.i) + bb)) + comp;
-  } else {
+                                       static_cast<size_t>(ib)) + comp;
+  } else if (kind <= 7u) {
     const uint32_t ring = max(c.ring, 1u);
     p = reinterpret_cast<const float*>(c.mid + (static_cast<size_t>(kind - 5u) * c.ring + (c.d + static_cast<uint32_t>(a)) % ring) * c.vec +
-                                       static_cast<size_t>(static_cast<int64_t>(c.i) + bb)) + comp;
+                                       static_cast<size_t>(ib)) + comp;
+  } else if (kind == 8u) {
+    p = c.zp + (a ? static_cast<size_t>(c.n) : static_cast<size_t>(ib));
+  } else {
+    p = c.zs + static_cast<size_t>(static_cast<int64_t>(c.j) + bb);
   }
   const float v = ok ? *p : 0.f;
   return ok ? v : (dflt == 0u ? kNegInf : (dflt == 1u ? 0.f : kEmpty));
@@ -787,6 +804,33 @@ __constant__ uint32_t kInOps[64] = {
     opd(4, 0, 1, 0, 0, 1, 2), opd(4, 0, 1, 0, 1, 1, 1),
     opd(5, 0, 0, 0, 0, 16, 2), opd(5, 0, 0, 0, 1, 16, 1), opd(5, 0, 1, 0, 0, 1 | 16, 2), opd(5, 0, 1, 0, 1, 1 | 16, 1),
     kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone};
+// outside sweep, cells (i,j+1) and (i,j) (and probs_multibranch of (i-1,j) from the ring)
+enum OutOp : int {
+  OO_QB0, OO_QB1, OO_PM2_A, OO_PM2_B, OO_W_A, OO_W_B, OO_SP1, OO_SP2, OO_ZTOT, OO_ZPI, OO_ZSJ0, OO_ZSJ1,
+  OO_QA0, OO_MBC0, OO_QA1, OO_MBC1, OO_CS0, OO_CS1 = OO_CS0 + 4, OO_IN0 = OO_CS1 + 4, OO_IN1 = OO_IN0 + 4,
+  OO_FAR0 = OO_IN1 + 4, OO_FAR1 = OO_FAR0 + 2, OO_P0 = OO_FAR1 + 2, OO_PN = OO_P0 + 2, OO_P1 = OO_PN + 2,
+  OO_E0 = OO_P1 + 2, OO_E1 = OO_E0 + 2, OO_COUNT = OO_E1 + 2
+};
+static_assert(OO_COUNT <= 64, "one lane per operand");
+__constant__ uint32_t kOutOps[64] = {
+    opd(0, T_QB, 0, 0, 0, 0, 0), opd(0, T_QB, 0, 1, 0, 1, 0),
+    // Pm2 / W of the cell right of the group's upper cell: (i, j+2) with a second cell, (i, j+1) without
+    opd(0, T_QM, 0, 2, 0, 1 | 128, 0), opd(0, T_QM, 0, 1, 0, 256 | 64, 0),
+    opd(0, T_ZRE, 0, 2, 0, 1 | 128, 0), opd(0, T_ZRE, 0, 1, 0, 256 | 64, 0),
+    opd(2, T_U, 1, -1, 0, 1 | 32, 0), opd(2, T_U, 0, -2, 0, 32, 0),
+    opd(8, 0, 1, 0, 0, 0, 1), opd(8, 0, 0, 0, 0, 0, 1), opd(9, 0, 0, 1, 0, 0, 1), opd(9, 0, 0, 2, 0, 1, 1),
+    opd(0, T_QA, 0, 0, 0, 0, 0), opd(0, T_MBC, 0, 0, 0, 0, 0), opd(0, T_QA, 0, 1, 0, 1, 0), opd(0, T_MBC, 0, 1, 0, 1, 0),
+    opd(1, T_CS4, 0, 0, 0, 0, 1), opd(1, T_CS4, 0, 0, 1, 0, 1), opd(1, T_CS4, 0, 0, 2, 0, 1), opd(1, T_CS4, 0, 0, 3, 0, 1),
+    opd(1, T_CS4, 0, 1, 0, 1, 1), opd(1, T_CS4, 0, 1, 1, 1, 1), opd(1, T_CS4, 0, 1, 2, 1, 1), opd(1, T_CS4, 0, 1, 3, 1, 1),
+    opd(1, T_IN4, 0, 0, 0, 0, 1), opd(1, T_IN4, 0, 0, 1, 0, 1), opd(1, T_IN4, 0, 0, 2, 0, 1), opd(1, T_IN4, 0, 0, 3, 0, 1),
+    opd(1, T_IN4, 0, 1, 0, 1, 1), opd(1, T_IN4, 0, 1, 1, 1, 1), opd(1, T_IN4, 0, 1, 2, 1, 1), opd(1, T_IN4, 0, 1, 3, 1, 1),
+    opd(4, 0, 0, 0, 0, 0, 2), opd(4, 0, 0, 0, 1, 0, 1), opd(4, 0, 1, 0, 0, 1, 2), opd(4, 0, 1, 0, 1, 1, 1),
+    opd(6, 0, 0, 0, 0, 16, 2), opd(6, 0, 0, 0, 1, 16, 1),
+    opd(6, 0, 1, -1, 0, 16 | 32 | 64, 2), opd(6, 0, 1, -1, 1, 16 | 32 | 64, 1),
+    opd(6, 0, 1, 0, 0, 16 | 1, 2), opd(6, 0, 1, 0, 1, 16 | 1, 1),
+    opd(7, 0, 0, 0, 0, 16, 2), opd(7, 0, 0, 0, 1, 16, 1), opd(7, 0, 1, 0, 0, 16 | 1, 2), opd(7, 0, 1, 0, 1, 16 | 1, 1),
+    kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone, kOpNone,
+    kOpNone, kOpNone, kOpNone, kOpNone};
 
 // ----------------------------------------------------------------------------
 // Two diagonals per launch.  The sweep's cost is its NUMBER of dependent launches and the
@@ -811,15 +855,19 @@ __device__ __forceinline__ void acc_product_2b(Acc& acc0, Acc& acc1, const float
                                                const float* __restrict__ B1, uint32_t len0,
                                                uint32_t len1, uint32_t t) {
   for (uint32_t k = t; k < len1; k += 4u * TPC) {
-    float x0[4], x1[4];
+    float x0[4], x1[4], va[4], vp[4], vr[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const uint32_t ku = k + static_cast<uint32_t>(u) * TPC;
-      const float a = ku < len1 ? A[ku] : kNegInf;
-      const float p = ku < len0 ? B0[ku] : kNegInf;
-      const float r = ku < len1 ? B1[ku] : kNegInf;
-      x0[u] = a + p;
-      x1[u] = a + r;
+      const uint32_t k1 = ku < len1 ? ku : 0u, k0 = ku < len0 ? ku : 0u;
+      va[u] = A[k1], vp[u] = B0[k0], vr[u] = B1[k1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t ku = k + static_cast<uint32_t>(u) * TPC;
+      x0[u] = ku < len0 ? va[u] + vp[u] : kNegInf;
+      x1[u] = ku < len1 ? va[u] + vr[u] : kNegInf;
     }
     acc_add4(acc0, x0[0], x0[1], x0[2], x0[3]);
     acc_add4(acc1, x1[0], x1[1], x1[2], x1[3]);
@@ -835,19 +883,23 @@ __device__ __forceinline__ void acc_product_2b_split(Acc& acc0, Acc& acc1, const
                                                      uint32_t jump, uint32_t lim0l, uint32_t lim0r,
                                                      uint32_t t) {
   for (uint32_t k = t; k < tot; k += 4u * TPC) {
-    float x0[4], x1[4];
+    float x0[4], x1[4], va[4], vp[4], vr[4];
+    bool ok0[4], ok1[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const uint32_t e = k + static_cast<uint32_t>(u) * TPC;
       const bool left = e < L;
       const uint32_t idx = left ? e : e + jump;
-      const bool v1 = e < tot;
-      const bool v0 = v1 && idx < (left ? lim0l : lim0r);
-      const float a = v1 ? A[idx] : kNegInf;
-      const float p = v0 ? B0[idx] : kNegInf;
-      const float r = v1 ? B1[idx] : kNegInf;
-      x0[u] = a + p;
-      x1[u] = a + r;
+      ok1[u] = e < tot;
+      ok0[u] = ok1[u] && idx < (left ? lim0l : lim0r);
+      const uint32_t i1 = ok1[u] ? idx : 0u, i0 = ok0[u] ? idx : 0u;
+      va[u] = A[i1], vp[u] = B0[i0], vr[u] = B1[i1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      x0[u] = ok0[u] ? va[u] + vp[u] : kNegInf;
+      x1[u] = ok1[u] ? va[u] + vr[u] : kNegInf;
     }
     acc_add4(acc0, x0[0], x0[1], x0[2], x0[3]);
     acc_add4(acc1, x1[0], x1[1], x1[2], x1[3]);
@@ -858,13 +910,16 @@ __device__ __forceinline__ void acc_product_split(Acc& a, const float* __restric
                                                   const float* __restrict__ B, uint32_t L, uint32_t tot,
                                                   uint32_t jump, uint32_t t) {
   for (uint32_t k = t; k < tot; k += 8u * TPC) {
-    float x[8];
+    float x[8], va[8], vb[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const uint32_t e = k + static_cast<uint32_t>(u) * TPC;
-      const uint32_t idx = e < L ? e : e + jump;
-      x[u] = e < tot ? A[idx] + B[idx] : kNegInf;
+      const uint32_t idx = e < tot ? (e < L ? e : e + jump) : 0u;
+      va[u] = A[idx], vb[u] = B[idx];
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; u++) x[u] = (k + static_cast<uint32_t>(u) * TPC < tot) ? va[u] + vb[u] : kNegInf;
     acc_add4(a, x[0], x[1], x[2], x[3]);
     acc_add4(a, x[4], x[5], x[6], x[7]);
   }
@@ -876,15 +931,19 @@ __device__ __forceinline__ void acc_product_2b_lo(Acc& acc0, Acc& acc1, const fl
                                                   const float* __restrict__ B1, uint32_t len0,
                                                   uint32_t len1, uint32_t lo1, uint32_t t) {
   for (uint32_t k = t; k < len1; k += 4u * TPC) {
-    float x0[4], x1[4];
+    float x0[4], x1[4], va[4], vp[4], vq[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const uint32_t ku = k + static_cast<uint32_t>(u) * TPC;
-      const float a = ku < len1 ? A[ku] : kNegInf;
-      const float p = ku < len0 ? B0[ku] : kNegInf;
-      const float r = (ku < len1 && ku >= lo1) ? B1[ku] : kNegInf;
-      x0[u] = a + p;
-      x1[u] = a + r;
+      const bool v1 = ku < len1, v0 = ku < len0, vr = v1 && ku >= lo1;
+      va[u] = A[v1 ? ku : 0u], vp[u] = B0[v0 ? ku : 0u], vq[u] = B1[vr ? ku : lo1 < len1 ? lo1 : 0u];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t ku = k + static_cast<uint32_t>(u) * TPC;
+      x0[u] = ku < len0 ? va[u] + vp[u] : kNegInf;
+      x1[u] = (ku < len1 && ku >= lo1) ? va[u] + vq[u] : kNegInf;
     }
     acc_add4(acc0, x0[0], x0[1], x0[2], x0[3]);
     acc_add4(acc1, x1[0], x1[1], x1[2], x1[3]);
@@ -1000,7 +1059,7 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(float* h
   float nqb = kNegInf, nsc = 0.f;  // (uf) lane 3c + s: sums_close of the pair near slot s of cell c encloses, its score
   bool ngeo = false;
   if constexpr (uf) {
-    const OpCtx oc{hbase_of(q), static_cast<uint64_t>(q.m[1] - q.m[0]), q.far, q.mid, i, j, d, n, ld, q.vec, b.ring,
+    const OpCtx oc{hbase_of(q), static_cast<uint64_t>(q.m[1] - q.m[0]), q.far, q.mid, q.zp, q.zs, i, j, d, n, ld, q.vec, b.ring,
                    has1, CONTRA, thr != 0u};
     const float ov = gather_operand(kInOps[lane], oc);
     // (issued right behind the gather, before anything waits for it: the near slots' sums_close and
@@ -1304,18 +1363,24 @@ __device__ __forceinline__ void acc_product_3(Acc& pm0, Acc& pmn, Acc& pm1,
                                               uint32_t lenn, bool do_n, bool do_1, uint32_t t) {
   // (lenn <= len0: where the neighbour's stream ends)
   for (uint32_t k = t; k < len0; k += 4u * TPC) {
-    float x0[4], xn[4], x1[4];
+    float x0[4], xn[4], x1[4], wi[4], qa[4], wm[4], qb[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const uint32_t ku = k + static_cast<uint32_t>(u) * TPC;
-      const bool v = ku < len0;
-      const float wi = v ? Wi[ku] : kNegInf;
-      const float wm = (ku < lenn && do_n) ? Wm[ku] : kNegInf;
-      const float qa = v ? Qa[ku] : kNegInf;
-      const float qb = (v && do_1 && ku >= 1u) ? Qb[ku] : kNegInf;
-      x0[u] = wi + qa;
-      xn[u] = wm + qa;
-      x1[u] = wi + qb;
+      const bool v = ku < len0, vn = ku < lenn && do_n, vb = v && do_1 && ku >= 1u;
+      const uint32_t kv = v ? ku : 0u;
+      wi[u] = Wi[kv], qa[u] = Qa[kv];
+      wm[u] = do_n ? Wm[vn ? ku : 0u] : kNegInf;  // (do_n, do_1: uniform)
+      qb[u] = do_1 ? Qb[vb ? ku : 1u] : kNegInf;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t ku = k + static_cast<uint32_t>(u) * TPC;
+      const bool v = ku < len0, vn = ku < lenn && do_n, vb = v && do_1 && ku >= 1u;
+      x0[u] = v ? wi[u] + qa[u] : kNegInf;
+      xn[u] = vn ? wm[u] + qa[u] : kNegInf;
+      x1[u] = vb ? wi[u] + qb[u] : kNegInf;
     }
     acc_add4(pm0, x0[0], x0[1], x0[2], x0[3]);
     acc_add4(pmn, xn[0], xn[1], xn[2], xn[3]);
@@ -1399,34 +1464,80 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(float* 
   const bool do0 = w0, do1 = uf ? w0 : (TPC == 64 || wv == 1u);
   const uint32_t lane = t & 63u;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float qb0 = sload(qb_r + row_i + j);
-  const float qb1 = has1 ? sload(qb_r + row_i + j1) : kNegInf;
   const uint32_t jt = has1 ? j1 : j;  // the upper cell of this group
+  float qb0 = kNegInf, qb1 = kNegInf;
   float pm2_nextt = kNegInf, w_nextt = kNegInf, sp_prev1 = kNegInf, sp_prev2 = kNegInf;
   float ztot = 0.f, zpi = 0.f, qa0 = kNegInf, mbc0 = kNegInf, zsj0 = 0.f, qa1 = kNegInf, mbc1 = kNegInf, zsj1 = 0.f;
-  float4 cs0 = zero4, cs1 = zero4;
-  if (w0) {  // (all from diagonals >= d+2, or statics)
-    if (jt + 1 < n) {
-      pm2_nextt = sload(pm2_r + row_i + jt + 1);  // Pm2(i, jt+1)
-      w_nextt = sload(w_r + row_i + jt + 1);      // W(i, jt+1)
+  float4 cs0 = zero4, cs1 = zero4, in0 = zero4, in1 = zero4;
+  Acc far0 = acc_empty(), far1 = acc_empty();
+  Acc mp0 = acc_empty(), mpn = acc_empty(), mp1 = acc_empty(), me0 = acc_empty(), me1 = acc_empty();
+  float nqb = kNegInf, npk = kNegInf, nsc = 0.f;  // (uf) lane 3c + s: closing pair of near slot s of cell c
+  bool ngeo = false;
+  if constexpr (uf) {
+    // (one vector gather for the ~46 uniform operands: gather_operand above)
+    const OpCtx oc{hbase_of(q), static_cast<uint64_t>(q.m[1] - q.m[0]), q.far, q.mid, q.zp, q.zs, i, j, d, n, ld, q.vec, b.ring,
+                   has1, CONTRA, thr != 0u};
+    const float ov = gather_operand(kOutOps[lane], oc);
+    {
+      // the near enclosing pairs (closing pairs of the last three diagonals): slot s of cell c in lane
+      // 3c + s; whether the cell is a pair at all is applied to the value below
+      const uint32_t c = lane / 3u, sl = lane - 3u * c;
+      const uint32_t cj = c == 0u ? j : j1;
+      uint32_t sa, sb;
+      Special<CONTRA>::slot(sl < kNear ? sl : 0u, sa, sb);
+      ngeo = lane < 6u && (c == 0u || has1) && sa < i && cj + 1u + sb < n;
+      if (ngeo) {
+        const uint32_t k = i - 1u - sa, l = cj + 1u + sb;
+        const size_t o = static_cast<size_t>(k) * ld + l;
+        nqb = q.m[T_QB][o];
+        npk = q.out[tri_off(n, l - k) + k];
+        nsc = q.m[T_NEAR4][4u * o + sl];  // (the closing pair's static: slot sl of (k,l))
+      }
     }
-    if (i >= 1 && has1) sp_prev1 = sload(sp_c + col_j + ld + i - 1);  // prefix of column j+1 up to row i-1
-    if (i >= 2) sp_prev2 = sload(sp_c + col_j + i - 2);               // prefix of column j up to row i-2
-    ztot = sload(q.zp + n);
-    zpi = sload(q.zp + i);
-    qa0 = sload(q.m[T_QA] + row_i + j);
-    mbc0 = sload(q.m[T_MBC] + row_i + j);
-    zsj0 = sload(q.zs + j + 1);
-    cs0 = sload4(cs4m + row_i + j);
-    if (has1) {
-      qa1 = sload(q.m[T_QA] + row_i + j1);
-      mbc1 = sload(q.m[T_MBC] + row_i + j1);
-      zsj1 = sload(q.zs + j1 + 1);
-      cs1 = sload4(cs4m + row_i + j1);
+    auto OP = [&](int x) { return lane_value(ov, x); };
+    qb0 = OP(OO_QB0), qb1 = OP(OO_QB1);
+    pm2_nextt = has1 ? OP(OO_PM2_A) : OP(OO_PM2_B);
+    w_nextt = has1 ? OP(OO_W_A) : OP(OO_W_B);
+    sp_prev1 = OP(OO_SP1), sp_prev2 = OP(OO_SP2);
+    ztot = OP(OO_ZTOT), zpi = OP(OO_ZPI), zsj0 = OP(OO_ZSJ0), zsj1 = OP(OO_ZSJ1);
+    qa0 = OP(OO_QA0), mbc0 = OP(OO_MBC0), qa1 = OP(OO_QA1), mbc1 = OP(OO_MBC1);
+    cs0 = make_float4(OP(OO_CS0), OP(OO_CS0 + 1), OP(OO_CS0 + 2), OP(OO_CS0 + 3));
+    cs1 = make_float4(OP(OO_CS1), OP(OO_CS1 + 1), OP(OO_CS1 + 2), OP(OO_CS1 + 3));
+    in0 = make_float4(OP(OO_IN0), OP(OO_IN0 + 1), OP(OO_IN0 + 2), OP(OO_IN0 + 3));
+    in1 = make_float4(OP(OO_IN1), OP(OO_IN1 + 1), OP(OO_IN1 + 2), OP(OO_IN1 + 3));
+    far0 = Acc{OP(OO_FAR0), OP(OO_FAR0 + 1)};
+    far1 = Acc{OP(OO_FAR1), OP(OO_FAR1 + 1)};
+    mp0 = Acc{OP(OO_P0), OP(OO_P0 + 1)};
+    mpn = Acc{OP(OO_PN), OP(OO_PN + 1)};
+    mp1 = Acc{OP(OO_P1), OP(OO_P1 + 1)};
+    me0 = Acc{OP(OO_E0), OP(OO_E0 + 1)};
+    me1 = Acc{OP(OO_E1), OP(OO_E1 + 1)};
+  } else {
+    qb0 = sload(qb_r + row_i + j);
+    qb1 = has1 ? sload(qb_r + row_i + j1) : kNegInf;
+    if (w0) {  // (all from diagonals >= d+2, or statics)
+      if (jt + 1 < n) {
+        pm2_nextt = sload(pm2_r + row_i + jt + 1);  // Pm2(i, jt+1)
+        w_nextt = sload(w_r + row_i + jt + 1);      // W(i, jt+1)
+      }
+      if (i >= 1 && has1) sp_prev1 = sload(sp_c + col_j + ld + i - 1);  // prefix of column j+1 up to row i-1
+      if (i >= 2) sp_prev2 = sload(sp_c + col_j + i - 2);               // prefix of column j up to row i-2
+      ztot = sload(q.zp + n);
+      zpi = sload(q.zp + i);
+      qa0 = sload(q.m[T_QA] + row_i + j);
+      mbc0 = sload(q.m[T_MBC] + row_i + j);
+      zsj0 = sload(q.zs + j + 1);
+      cs0 = sload4(cs4m + row_i + j);
+      if (has1) {
+        qa1 = sload(q.m[T_QA] + row_i + j1);
+        mbc1 = sload(q.m[T_MBC] + row_i + j1);
+        zsj1 = sload(q.zs + j1 + 1);
+        cs1 = sload4(cs4m + row_i + j1);
+      }
     }
+    in0 = do0 ? sload4(in4m + row_i + j) : zero4;
+    in1 = (has1 && do1) ? sload4(in4m + row_i + j1) : zero4;
   }
-  const float4 in0 = do0 ? sload4(in4m + row_i + j) : zero4;
-  const float4 in1 = (has1 && do1) ? sload4(in4m + row_i + j1) : zero4;
   const bool paired0 = qb0 > kNegInf, paired1 = qb1 > kNegInf;  // (uniform)
 
   Acc acc[NA];
@@ -1434,28 +1545,11 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(float* 
   for (int x = 0; x < NA; x++) acc[x] = acc_empty();
   // [3] [4] enclosing 2-loops of (i,j) and (i,j+1): one wave each
   float nx = kNegInf;  // (uf) lane 3c + s: near slot s of cell c
-  Acc far0 = acc_empty(), far1 = acc_empty();
   if constexpr (uf) {
-    if (w0) {
-      // near part (the enclosing pairs of the last three diagonals): slot s of cell c in lane 3c + s
-      far0 = load_far(q, d, i);
-      if (has1) far1 = load_far(q, d + 1u, i);
-      const uint32_t c = lane / 3u, sl = lane - 3u * c;
-      if (lane < 6u && (c == 0u ? paired0 : paired1)) {
-        const uint32_t cj = c == 0u ? j : j1;
-        const float qbc = c == 0u ? qb0 : qb1;
-        uint32_t a, bb;
-        Special<CONTRA>::slot(sl, a, bb);
-        if (a < i && cj + 1u + bb < n) {
-          const uint32_t k = i - 1u - a, l = cj + 1u + bb;
-          const size_t o = static_cast<size_t>(k) * ld + l;
-          const float x = q.m[T_QB][o];
-          const float pkl = q.out[tri_off(n, l - k) + k];
-          const float sc = q.m[T_NEAR4][4u * o + sl];  // (the closing pair's static: slot sl of (k,l))
-          if (x > kNegInf) nx = ((pkl + qbc) - x) + sc;
-        }
-      }
-    }
+    // near part (the enclosing pairs of the last three diagonals), gathered with the operands above
+    const uint32_t c = lane / 3u;
+    const float qbc = c == 0u ? qb0 : qb1;
+    if (ngeo && (c == 0u ? paired0 : paired1) && nqb > kNegInf) nx = ((npk + qbc) - nqb) + nsc;
   } else {
   if (paired0 && do0)
     outer_block<CONTRA, 64>(b, q, acc[3], i, j, lane, qb0, in0, load_win64(q.pk, static_cast<int>(i) - 31),
@@ -1494,11 +1588,11 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(float* 
   }
   if (thr != 0u && w0) {
     // (the ring rows of diagonals d, d+1 belong to this band; cells past the matrix are never read)
-    const Acc p0 = load_mid(q, b.ring, 1u, d, i);
-    const Acc pn = (i >= 1 && j < n - 1) ? load_mid(q, b.ring, 1u, d + 1u, i - 1u) : acc_empty();
-    const Acc p1 = has1 ? load_mid(q, b.ring, 1u, d + 1u, i) : acc_empty();
-    const Acc e0 = load_mid(q, b.ring, 2u, d, i);
-    const Acc e1 = has1 ? load_mid(q, b.ring, 2u, d + 1u, i) : acc_empty();
+    const Acc p0 = uf ? mp0 : load_mid(q, b.ring, 1u, d, i);
+    const Acc pn = uf ? mpn : ((i >= 1 && j < n - 1) ? load_mid(q, b.ring, 1u, d + 1u, i - 1u) : acc_empty());
+    const Acc p1 = uf ? mp1 : (has1 ? load_mid(q, b.ring, 1u, d + 1u, i) : acc_empty());
+    const Acc e0 = uf ? me0 : load_mid(q, b.ring, 2u, d, i);
+    const Acc e1 = uf ? me1 : (has1 ? load_mid(q, b.ring, 2u, d + 1u, i) : acc_empty());
     if (t == 0u) {
       acc_merge(acc[0], p0);
       acc_merge(acc[1], pn);
