@@ -717,7 +717,9 @@ def main():
             checked += 1
             if golden_digest(got) != info["sha256"] or len(my_seqs[x]) != info["n"]:
                 failed += 1
-    prf = per_rank_fields(local_elapsed / max(steps, 1), checked)
+    # (a rank's OWN pass time: its timed steps, each synchronised; `local_elapsed` ends behind the barrier
+    # and so is the slowest rank's time on every rank)
+    prf = per_rank_fields(float(np.mean(step_s)) if step_s else local_elapsed / max(steps, 1), checked)
     if world > 1:
         # every rank checks the golden members of ITS shard; rank 0 reports the sum
         cf = torch.tensor([checked, failed], dtype=torch.int64,
