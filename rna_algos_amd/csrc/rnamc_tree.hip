@@ -1042,6 +1042,48 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(float* h
              do1 = uf ? w0 : (TPC == 64 || wv == (TPC == 128 ? 0u : 2u));
   const uint32_t lane = t & 63u;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  Acc acc[NA];
+#pragma unroll
+  for (int x = 0; x < NA; x++) acc[x] = acc_empty();
+  // (banded sweeps: sums_external's row 0 and column n-1 are k_tree_ext's, a band behind)
+  const bool ext_side = b.ring != 0u;
+  const bool zs0 = !ext_side && j == n - 1, zs1 = !ext_side && has1 && j1 == n - 1;  // which cell sits in column n-1
+  const bool row0 = !ext_side && i == 0;
+  // [3] [4] sums_multibranch of (i,j) and (i,j+1): k = i+1 .. j-1 | j, Q1(i,k-1) + Zr_mb(k,j | j+1)
+  // (the k = i+1 term of the second reads a cell of this launch: left out, it carries Q1(i,i) = -inf)
+  auto products = [&]() {
+#ifdef RNAMC_DEBUG_KNOBS
+    if (b.debug & 2) return;
+#endif
+    if (thr != 0u) {
+      // idx: Q1(i, i+1+idx) [span idx+1] + Zr_mb(i+2+idx, j | j+1) [span d-2-idx | d-1-idx]
+      if (has1)
+        acc_product_2b_split<TPC>(acc[3], acc[4], q.m[T_Q1R] + row_i + i + 1, q.m[T_ZRM] + col_j + i + 2,
+                                  q.m[T_ZRM] + col_j + ld + i + 2, d - thr, 2u * (d - thr),
+                                  (thr - 1u) - (d - thr), d - 1u - thr, d - 2u, t);
+      else  // idx': Q1(i, i+idx') [span idx'] + Zr_mb(i+1+idx', j) [span d-1-idx']
+        acc_product_split<TPC>(acc[3], q.m[T_Q1R] + row_i + i, q.m[T_ZRM] + col_j + i + 1, d - thr,
+                               (d - thr) + (d - 1u - thr), thr - (d - thr), t);
+    } else if (has1) {
+      if (d >= 2)
+        acc_product_2b<TPC>(acc[3], acc[4], q.m[T_Q1R] + row_i + i + 1, q.m[T_ZRM] + col_j + i + 2,
+                            q.m[T_ZRM] + col_j + ld + i + 2, d - 2, d - 1, t);
+      // (k = i+1 of the first, left out to keep both streams on the same k: q1_ii, added below)
+    } else if (d >= 2) {
+      acc_product<TPC>(acc[3], q.m[T_Q1R] + row_i + i, q.m[T_ZRM] + col_j + i + 1, d - 1, t);
+    }
+    // [5] [6] Z(0,j), Z(0,j+1): k >= 1 | 2, Zr_ext(k,.) + Z(0,k-1)
+    if (row0) {
+      if (j >= 1) acc_product<TPC>(acc[5], q.m[T_ZRE] + col_j + 1, q.zp + 1, j, t);
+      if (has1 && j1 >= 2) acc_product<TPC>(acc[6], q.m[T_ZRE] + col_j + ld + 2, q.zp + 2, j1 - 1, t);
+    }
+    // [7] column n-1 cell of this group: l = i+1 .. (zs0: n-2 | zs1: n-3), Qa(i,l) + Z(l+1,n-1)
+    //     (zs1: l = j = n-2 is this launch's own cell (i,j))
+    if ((zs0 || zs1) && d >= 1) acc_product<TPC>(acc[7], q.m[T_QA] + row_i + i + 1, q.zs + i + 2, d - 1, t);
+    // [8] zs1: the neighbour (i+1,n-1)'s own sum, l = i+2 .. n-2
+    if (zs1 && d >= 1)
+      acc_product<TPC>(acc[8], q.m[T_QA] + row_i + ld + i + 2, q.zs + i + 3, d - 1, t);
+  };
   // every uniform operand of the cell pair: one vector gather in the banded sweep's launches (uf:
   // gather_operand above), scalar loads in the other variants
   float mbc0 = kNegInf, mbc1 = kNegInf, mbcn = kNegInf, hp0 = kNegInf, hp1 = kNegInf, hpn = kNegInf;
@@ -1050,10 +1092,6 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(float* h
   float qm0 = kNegInf, qm1 = kNegInf, qmn = kNegInf;
   float zr_e_prev = kNegInf, zr_m_prev = kNegInf, zr_e_prevn = kNegInf, zr_m_prevn = kNegInf;
   float u_next0 = kNegInf, u_nextn = kNegInf;  // U(i+1, j), U(i+2, j+1)
-  // (banded sweeps: sums_external's row 0 and column n-1 are k_tree_ext's, a band behind)
-  const bool ext_side = b.ring != 0u;
-  const bool zs0 = !ext_side && j == n - 1, zs1 = !ext_side && has1 && j1 == n - 1;  // which cell sits in column n-1
-  const bool row0 = !ext_side && i == 0;
   float zs_a = 0.f, zs_last = 0.f, zp1 = 0.f, q1_ii = kNegInf;
   Acc far0 = acc_empty(), farn = acc_empty(), far1 = acc_empty(), mid0 = acc_empty(), mid1 = acc_empty();
   float nqb = kNegInf, nsc = 0.f;  // (uf) lane 3c + s: sums_close of the pair near slot s of cell c encloses, its score
@@ -1076,6 +1114,9 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(float* h
         nsc = q.m[T_NEAR4][4u * (static_cast<size_t>(ci) * ld + cj) + sl];
       }
     }
+    // (the product streams need none of the operands: their loads go out behind the gather, and their
+    // sums run while it is in flight — one round trip for both)
+    products();
     auto OP = [&](int x) { return lane_value(ov, x); };
     mbc0 = OP(IO_MBC0), mbc1 = OP(IO_MBC1), mbcn = OP(IO_MBCN);
     hp0 = OP(IO_HP0), hp1 = OP(IO_HP1), hpn = OP(IO_HPN);
@@ -1143,9 +1184,6 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(float* h
   }
 #endif
 
-  Acc acc[NA];
-#pragma unroll
-  for (int x = 0; x < NA; x++) acc[x] = acc_empty();
   // [0] [1] [2] closing-pair blocks of (i,j), (i+1,j+1), (i,j+1): one wave each
   float nx = kNegInf;  // (uf) lane 3c + s: near slot s of cell c
   if constexpr (uf) {
@@ -1166,41 +1204,7 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(float* h
     pair_block<CONTRA, 64>(b, q, acc[2], i, j1, lane, hp1, qm1 + mbc1, cs1,
                            load_win64(q.pk, static_cast<int>(i)), load_win64(q.pk, static_cast<int>(j) - 30));
   }
-  // [3] [4] sums_multibranch of (i,j) and (i,j+1): k = i+1 .. j-1 | j, Q1(i,k-1) + Zr_mb(k,j | j+1)
-  // (the k = i+1 term of the second reads a cell of this launch: left out, it carries Q1(i,i) = -inf)
-#ifdef RNAMC_DEBUG_KNOBS
-  if (!(b.debug & 2))
-#endif
-  {
-    if (thr != 0u) {
-      // idx: Q1(i, i+1+idx) [span idx+1] + Zr_mb(i+2+idx, j | j+1) [span d-2-idx | d-1-idx]
-      if (has1)
-        acc_product_2b_split<TPC>(acc[3], acc[4], q.m[T_Q1R] + row_i + i + 1, q.m[T_ZRM] + col_j + i + 2,
-                                  q.m[T_ZRM] + col_j + ld + i + 2, d - thr, 2u * (d - thr),
-                                  (thr - 1u) - (d - thr), d - 1u - thr, d - 2u, t);
-      else  // idx': Q1(i, i+idx') [span idx'] + Zr_mb(i+1+idx', j) [span d-1-idx']
-        acc_product_split<TPC>(acc[3], q.m[T_Q1R] + row_i + i, q.m[T_ZRM] + col_j + i + 1, d - thr,
-                               (d - thr) + (d - 1u - thr), thr - (d - thr), t);
-    } else if (has1) {
-      if (d >= 2)
-        acc_product_2b<TPC>(acc[3], acc[4], q.m[T_Q1R] + row_i + i + 1, q.m[T_ZRM] + col_j + i + 2,
-                            q.m[T_ZRM] + col_j + ld + i + 2, d - 2, d - 1, t);
-      // (k = i+1 of the first, left out to keep both streams on the same k: q1_ii, added below)
-    } else if (d >= 2) {
-      acc_product<TPC>(acc[3], q.m[T_Q1R] + row_i + i, q.m[T_ZRM] + col_j + i + 1, d - 1, t);
-    }
-    // [5] [6] Z(0,j), Z(0,j+1): k >= 1 | 2, Zr_ext(k,.) + Z(0,k-1)
-    if (row0) {
-      if (j >= 1) acc_product<TPC>(acc[5], q.m[T_ZRE] + col_j + 1, q.zp + 1, j, t);
-      if (has1 && j1 >= 2) acc_product<TPC>(acc[6], q.m[T_ZRE] + col_j + ld + 2, q.zp + 2, j1 - 1, t);
-    }
-    // [7] column n-1 cell of this group: l = i+1 .. (zs0: n-2 | zs1: n-3), Qa(i,l) + Z(l+1,n-1)
-    //     (zs1: l = j = n-2 is this launch's own cell (i,j))
-    if ((zs0 || zs1) && d >= 1) acc_product<TPC>(acc[7], q.m[T_QA] + row_i + i + 1, q.zs + i + 2, d - 1, t);
-    // [8] zs1: the neighbour (i+1,n-1)'s own sum, l = i+2 .. n-2
-    if (zs1 && d >= 1)
-      acc_product<TPC>(acc[8], q.m[T_QA] + row_i + ld + i + 2, q.zs + i + 3, d - 1, t);
-  }
+  if constexpr (!uf) products();
   if (t == 0u) acc_add(acc[3], q1_ii);
   if (thr != 0u && w0) {
     const Acc m0 = uf ? mid0 : load_mid(q, b.ring, 0u, d, i);
