@@ -245,7 +245,9 @@ int rnamc_ctx_set_params(rnamc_ctx* ctx, const rnamc_params* params);
  * workgroups of the previous launch, default 1), "tree_waves" (waves a tree-order launch may hold
  * at once when it picks threads per cell, default 5120), "tree_short" (sums of at most this many
  * terms take one wave per cell, default 256), "tree_ahead_waves" (waves up to which the ahead role
- * takes one wave per cell instead of one per row, default 16384).  Every knob is per context. */
+ * takes one wave per cell instead of one per row, default 16384), "tree_side_stream" (0: probe
+ * whether the side stream runs beside the caller's stream and sweep unbanded if not — the default;
+ * 1 / 2: take it as concurrent / serialised without probing).  Every knob is per context. */
 int rnamc_ctx_set(rnamc_ctx* ctx, const char* name, int64_t value);
 
 /* mccaskill_algo over a batch (src/mccaskill_algo.rs:247-280 for each record, as
@@ -334,6 +336,12 @@ typedef struct rnamc_batch_stats {
    *   small: k_outside<.,7>  all three roles in one kernel (launches too small to split) */
   uint64_t launches_outside_main, launches_outside_tail, launches_outside_small;
   double ms_outside_main, ms_outside_tail, ms_outside_small;
+  /* tree-order mode, banded sweep: does the context's side stream (mid-field products) run BESIDE
+   * the caller's stream?  0 not probed (no banded call yet), 1 yes, 2 no — the two share a
+   * hardware queue (the process holds too many streams): the sweep then runs unbanded (slower on
+   * long sequences, never wrong).  Probed once per context and stream, ~0.2 ms
+   * (rnamc_tree.hip, tree_side_stream_probe). */
+  uint64_t tree_side_stream;
 } rnamc_batch_stats;
 int rnamc_ctx_last_stats(rnamc_ctx* ctx, rnamc_batch_stats* out);
 /* The same with the caller's idea of the struct size: copies min(out_bytes, sizeof) bytes, so a

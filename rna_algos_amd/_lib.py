@@ -51,7 +51,7 @@ class BatchStats(C.Structure):
         ("launches_outside_main", C.c_uint64), ("launches_outside_tail", C.c_uint64),
         ("launches_outside_small", C.c_uint64),
         ("ms_outside_main", C.c_double), ("ms_outside_tail", C.c_double),
-        ("ms_outside_small", C.c_double),
+        ("ms_outside_small", C.c_double), ("tree_side_stream", C.c_uint64),
     ]
 
 

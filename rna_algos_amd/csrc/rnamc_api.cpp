@@ -82,6 +82,12 @@ struct rnamc_ctx {
   int64_t tree_ahead = 1;
   TreePolicy tree_pol;  // launch shapes of the tree-order sweep ("tree_waves", "tree_short", ...)
   hipStream_t bulk_stream = nullptr;  // k_tree_mid, beside the sweep (lowest priority)
+  // does bulk_stream run beside the stream of the last banded call?  (probed once per stream:
+  // tree_side_stream_probe; 0 unknown, 1 yes, 2 no -> unbanded sweeps on that stream)
+  hipStream_t side_probed_for = nullptr;
+  bool side_probed = false;
+  int side_verdict = 0;
+  int64_t tree_side_force = 0;  // knob "tree_side_stream": 0 probe, 1 take it as concurrent, 2 as serialised
   int64_t tree_debug = 0;  // (RNAMC_DEBUG_KNOBS builds: bit 0 no 2-loops, 1 no products, 2 empty kernels)
   int64_t group_max_seqs = 8192;
   int64_t group_max_nt = 2ll << 20;  // a group holds ~2M nucleotides (or 64 GB of DP state)
@@ -734,6 +740,22 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     HIPCHK(hipStreamCreateWithPriority(&c->bulk_stream, hipStreamNonBlocking, lo));
   }
+  if (band) {
+    // The banded sweep lives on the mid-field kernels running BESIDE it.  Whether the side stream
+    // owns a hardware queue depends on what else the process created (round 3: created late it
+    // shared the sweep's queue, 157 ms instead of 49.5): detected, not assumed — once per caller
+    // stream; a serialised side stream means the unbanded sweep (slower, never wrong).
+    if (c->tree_side_force == 1 || c->tree_side_force == 2) {  // (knob "tree_side_stream": the verdict is given)
+      c->side_verdict = static_cast<int>(c->tree_side_force);
+      c->side_probed = true;
+      c->side_probed_for = nullptr;
+    } else if (!c->side_probed || c->side_probed_for != st) {
+      c->side_verdict = tree_side_stream_probe(st, c->bulk_stream);
+      c->side_probed = true;
+      c->side_probed_for = st;
+    }
+    if (c->side_verdict == 2) band = 0u;
+  }
   std::vector<TreeSeq>& tseqs = c->h_tseqs;
   tseqs.clear();
   tseqs.reserve(n_seqs);
@@ -998,6 +1020,7 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
       if (rc) return rc;
     }
   }
+  c->stats.tree_side_stream = static_cast<uint64_t>(c->side_probed ? c->side_verdict : 0);
   c->stats.n_groups = n_groups;
   c->stats.workspace_bytes = c->ws_floats * sizeof(float);
   if (prof) {
@@ -1216,6 +1239,9 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
   const std::string k(name);
   if (k == "summation_mode" && (value == 0 || value == 1)) {
     c->summation_mode = value;
+  } else if (k == "tree_side_stream" && value >= 0 && value <= 2) {
+    c->tree_side_force = value;
+    c->side_probed = false;
   } else if (k == "tree_waves" && value >= 64) {
     c->tree_pol.waves = static_cast<uint64_t>(value);
   } else if (k == "tree_short" && value >= 1) {

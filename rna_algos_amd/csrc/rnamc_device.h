@@ -172,6 +172,11 @@ void launch_tree_mid(const TreeBatch& b, bool outside, uint32_t dlo, uint32_t dh
 // sums_external's first row and last column of a banded sweep, diagonals [dlo, dhi] (in order)
 void launch_tree_ext(const TreeBatch& b, bool contra, uint32_t dlo, uint32_t dhi, uint32_t max_n,
                      uint32_t nseq, hipStream_t st);
+// Does `side` run beside `main`?  A bounded spin (~120 us of s_memtime ticks, every wave exits) on
+// `side`, a trivial kernel on `main` behind it in submission order, events around the latter: if
+// the trivial kernel only ends when the spin does, the two streams share a hardware queue.
+// Returns 1 (concurrent), 2 (serialised), 0 on any HIP error.  Synchronises both streams.
+int tree_side_stream_probe(hipStream_t main, hipStream_t side);
 // per-cell statics (hairpin / multibranch-close / accessible scores, 2-loop sides), once per group
 void launch_tree_static(const TreeBatch& b, bool contra, uint32_t nseq, uint32_t max_n, hipStream_t st);
 void launch_tree_finalize(const TreeBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st);

@@ -2128,6 +2128,43 @@ void launch_tree_ext(const TreeBatch& b, bool contra, uint32_t dlo, uint32_t dhi
     hipLaunchKernelGGL(k_tree_ext<false>, dim3(2, nseq, 1), dim3(1024), lds, st, b, dlo, dhi, use_lds ? 1 : 0);
 }
 
+namespace {
+__global__ void k_tree_spin(unsigned long long ticks, unsigned int* sink) {
+  // bounded: every wave leaves after `ticks` of the 100-MHz real-time counter (or 2^20 rounds)
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned int rounds = 0;
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks && rounds < (1u << 20)) {
+    __builtin_amdgcn_s_sleep(32);
+    rounds++;
+  }
+  if (sink && rounds == 0xffffffffu) *sink = rounds;
+}
+}  // namespace
+
+int tree_side_stream_probe(hipStream_t main, hipStream_t side) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int verdict = 0;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    if (e0) (void)hipEventDestroy(e0);
+    return 0;
+  }
+  do {
+    if (hipStreamSynchronize(main) != hipSuccess || hipStreamSynchronize(side) != hipSuccess) break;
+    constexpr unsigned long long kSpinTicks = 12000;  // 120 us at 100 MHz
+    hipLaunchKernelGGL(k_tree_spin, dim3(1), dim3(64), 0, side, kSpinTicks, static_cast<unsigned int*>(nullptr));
+    if (hipEventRecord(e0, main) != hipSuccess) break;
+    hipLaunchKernelGGL(k_tree_spin, dim3(1), dim3(64), 0, main, 0ull, static_cast<unsigned int*>(nullptr));
+    if (hipEventRecord(e1, main) != hipSuccess) break;
+    if (hipStreamSynchronize(main) != hipSuccess || hipStreamSynchronize(side) != hipSuccess) break;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) break;
+    verdict = ms < 0.06f ? 1 : 2;  // (a trivial kernel behind a free queue: ~10 us)
+  } while (false);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return verdict;
+}
+
 void launch_tree_finalize(const TreeBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st) {
   const uint64_t elems = static_cast<uint64_t>(max_n) * (max_n + 1) / 2;
   uint32_t gx = static_cast<uint32_t>(std::min<uint64_t>((elems + 1023) / 1024, 1024));
