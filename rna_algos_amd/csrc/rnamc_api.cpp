@@ -77,6 +77,10 @@ struct rnamc_ctx {
   // tree mode: width of a band of diagonals whose products take their mid-field from k_tree_mid
   // (a multiple of 32, at most 128; 0: every launch walks its sums whole)
   int64_t tree_band = 64;
+  // tree mode: lane-per-cell sweeps (rnamc_tree_lane.h) — 0 never, 1 for batches (a call of at least
+  // tree_lane_min_nt nucleotides whose sweeps are banded), 2 always; bit 2 (value 4) set: inside sweep only
+  int64_t tree_lane = 0;
+  int64_t tree_lane_min_nt = 65536;
   // tree mode, banded sweeps: the far part of a launch's 2-loop blocks is summed by extra
   // workgroups of the previous launch (rnamc_tree.hip, Ahead)
   int64_t tree_ahead = 1;
@@ -683,6 +687,26 @@ void build_tree_tabs(const rnamc_params& P, TreeTabs& T) {
       T.len[1][p] = (s0 + se) + f.interior_scores_len_cumulative[len - 2u];
     }
   }
+  // the generic slots by a + b (lane-per-cell sweeps); classes as slot_class of rnamc_tree.hip
+  for (int m = 0; m < 2; m++) {
+    uint32_t cnt = 0;
+    for (uint32_t s = 0; s <= 30u; s++) {
+      for (uint32_t a = 0; a <= s; a++) {
+        const uint32_t b = s - a;
+        const bool special = m == 0 ? ((a + b <= 1u) || (a >= 1u && a <= 2u && b >= 1u && b <= 2u)) : (a <= 1u && b <= 1u);
+        if (special) continue;
+        const uint32_t p = a <= 15u ? a * 32u + b : (30u - a) * 32u + b + a + 1u;  // (probe_slot's inverse)
+        const uint32_t cls = ((a == 0u) != (b == 0u)) ? 0u
+                             : (a == 1u || b == 1u) ? 1u
+                             : ((a == 2u && b == 3u) || (a == 3u && b == 2u)) ? 2u : 3u;
+        T.gslot[m][cnt] = a | (b << 5) | (cls << 10);
+        T.glen[m][cnt] = T.len[m][p];
+        cnt++;
+      }
+      T.gcount[m][s] = cnt;
+    }
+    T.gcount[m][31] = cnt;
+  }
 }
 
 int ensure_tree_tabs(rnamc_ctx* c, hipStream_t st) {
@@ -755,6 +779,13 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
       c->side_probed_for = st;
     }
     if (c->side_verdict == 2) band = 0u;
+  }
+  // lane-per-cell sweeps: what a batch's fat launches want (a lone sequence keeps the wave-per-cell chain)
+  uint32_t lane_mode = 0u;
+  {
+    const int64_t mode = c->tree_lane & 3;
+    if (band && (mode == 2 || (mode == 1 && offsets[n_seqs] - offsets[0] >= static_cast<uint64_t>(c->tree_lane_min_nt) && n_seqs > 1)))
+      lane_mode = (c->tree_lane & 4) ? 1u : 3u;
   }
   std::vector<TreeSeq>& tseqs = c->h_tseqs;
   tseqs.clear();
@@ -858,6 +889,7 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
     b.debug = static_cast<int>(c->tree_debug);
 #endif
     b.ring = 2u * band;
+    b.lane = lane_mode;
     auto active = [&](uint32_t d) {  // sequences with n > d form a prefix of the group
       uint32_t lo = 0, hi = nseq;
       while (lo < hi) {
@@ -926,6 +958,12 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
           if (x >= 3) HIPCHK(hipStreamWaitEvent(st, c->ev_b[x % ering], 0));
         }
         const uint32_t thr = x >= 3 ? (x - 1) * band : 0u;
+        if (lane_mode & 1u) {
+          launch_tlane_inside(b, contra, d, gmax, active(d), thr, st);
+          c->stats.launches_inside++;
+          d++;
+          continue;
+        }
         const bool pair = (d % 2u == 0u) && d + 1 < gmax;
         // the next launch's diagonals: their 2-loop blocks' far parts ride in this launch
         const uint32_t nd0 = d + (pair ? 2u : 1u);
@@ -1250,6 +1288,12 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     c->tree_pol.mid_wgs = static_cast<uint32_t>(std::min<int64_t>(value, 1 << 20));
   } else if (k == "tree_ahead_waves" && value >= 0) {
     c->tree_pol.ahead_waves = static_cast<uint64_t>(value);
+  } else if (k == "tree_lane" && value >= 0 && value <= 7) {
+    c->tree_lane = value;
+  } else if (k == "tree_lane_min_nt" && value >= 0) {
+    c->tree_lane_min_nt = value;
+  } else if (k == "tree_xcd_rows" && (value == 0 || value == 1)) {
+    c->tree_pol.xcd_rows = static_cast<uint32_t>(value);
   } else if (k == "tree_ahead") {
     c->tree_ahead = value;
   } else if (k == "tree_two") {

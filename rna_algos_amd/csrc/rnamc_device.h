@@ -101,15 +101,28 @@ enum TreeMat : int {
   T_ACCS = 14, // accessible score (static)                                  row
   T_CS4 = 15,  // float4 per cell, row: the pair as CLOSING pair of a generic 2-loop, by class (static)
   T_IN4 = 19,  // float4 per cell, row: the pair as ENCLOSED pair (static)
-  T_NEAR4 = 23,  // float4 per cell, row: scores of the pair's three nearest explicit 2-loops,
-                 // enclosed pair (i+1,j-1), (i+1,j-2), (i+2,j-1) (static; .w unused)
-  T_COUNT = 27
+  T_NEAR4 = 23,  // float4 per cell, row: scores of the explicit small 2-loops this pair CLOSES, slots 0..3 of
+                 // Special<>::slot: enclosed pair (i+1,j-1), (i+1,j-2), (i+2,j-1), (i+2,j-2) (static)
+  T_NEAR8 = 27,  // float4 per cell, row: slots 4..6 (Turner: 1x2, 2x1, 2x2; .w unused) (static)
+  // lane-per-cell sweeps (rnamc_tree_lane.h), DIAGONAL-major: cell (i, j) at [(j - i) * ld + i], so that
+  // the 64 consecutive rows a wave holds read and write consecutive floats.  In those sweeps the four
+  // T_X4 planes are diagonal-major too (their only readers are the sweeps' own 2-loop sums).
+  T_QB_D = 31,   // sums_close
+  T_Q1_D = 32,   // sums_1ormore_basepairs
+  T_ZRM_D = 33,  // sums_rightmost_basepairs_multibranch | outside: R
+  T_W_D = 34,    // outside: W
+  T_COUNT = 35
 };
 // Length-dependent part of a generic 2-loop score per probe slot (rnamc_tree.hip, probe_slot),
 // derived from rnamc_params on the host (rnamc_api.cpp, build_tree_tabs).  Model index 0 Turner,
 // 1 CONTRAfold.
 struct TreeTabs {
   float len[2][512];
+  // lane-per-cell sweeps: the generic slots in order of a + b (a prefix of the list is what a cell of a
+  // given span can enclose): a | b << 5 | class << 10, the slot's length term, slots with a + b <= s
+  uint32_t gslot[2][512];
+  float glen[2][512];
+  uint32_t gcount[2][32];
 };
 struct TreeSeq {
   uint32_t n, ld;
@@ -138,6 +151,7 @@ struct TreeBatch {
   int allows_short_hairpins;
   int debug;  // timing experiments (builds with -DRNAMC_DEBUG_KNOBS only; 0 otherwise)
   uint32_t ring;  // diagonals the mid-field ring holds (twice the band width; 0: no banding)
+  uint32_t lane;  // bit 0: the inside sweep runs lane-per-cell (T_X4 diagonal-major in it), bit 1: the outside sweep
 };
 // Launch-shape policy of the tree-order sweep, per context (rnamc_ctx_set "tree_waves",
 // "tree_short", "tree_ahead_waves", "tree_mid_wgs"): passed to every launch, no process globals.
@@ -146,6 +160,8 @@ struct TreePolicy {
   uint32_t short_terms = 256;       // sums up to this many terms take one wave per cell
   uint64_t ahead_waves = 16384;    // waves up to which the ahead role takes one wave per CELL (a lone sequence;
                                     // beyond — batches — one per row: 8 % faster there, profiles/r04_tree_on_batches.txt)
+  uint32_t xcd_rows = 0;            // != 0: workgroup ids of a sweep launch are dealt so that runs of 8 workgroups
+                                    // (32 rows of a sequence) share an XCD, rotated by sequence (see xcd_chunk)
   uint32_t mid_wgs = 0;             // workgroups of a k_tree_mid launch; 0: by the longest sequence (256 below
                                     // 6 144 nt, 512 below 12 288, 1 024 beyond: from ~8 000 nt on the mid-field
                                     // products, not the launch chain, set the sweep's time: profiles/r04_tree_long.txt)
@@ -179,6 +195,11 @@ void launch_tree_ext(const TreeBatch& b, bool contra, uint32_t dlo, uint32_t dhi
 int tree_side_stream_probe(hipStream_t main, hipStream_t side);
 // per-cell statics (hairpin / multibranch-close / accessible scores, 2-loop sides), once per group
 void launch_tree_static(const TreeBatch& b, bool contra, uint32_t nseq, uint32_t max_n, hipStream_t st);
+// lane-per-cell sweeps of a batch (rnamc_tree_lane.h): one diagonal per launch, a lane per cell
+void launch_tlane_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq, uint32_t thr,
+                         hipStream_t st);
+void launch_tlane_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq, uint32_t thr,
+                          hipStream_t st);
 void launch_tree_finalize(const TreeBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st);
 
 }  // namespace rnamc

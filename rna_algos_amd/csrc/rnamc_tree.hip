@@ -314,10 +314,28 @@ constexpr uint32_t kNear = 3u;
 #endif
 constexpr int kFarNG = RNAMC_FAR_NG;  // gathers per lane in flight in the far parts (8 slots per lane)
 struct Ahead {
-  uint32_t flags;        // bit 0: this launch's blocks take their far part from q.far
+  uint32_t flags;        // bit 0: this launch's blocks take their far part from q.far; bit 1: one ahead
+                         // wave per CELL; bit 2: workgroup ids dealt by xcd_chunk
   uint32_t main_blocks;  // workgroups of the launch proper; the rest are the ahead role
   uint32_t nd0, nd_count;  // diagonals of the next launch (nd_count = 0: no ahead role)
 };
+
+// Workgroups go to the 8 XCDs round-robin by linear id (x fastest), so with 4 rows to a workgroup
+// neighbouring rows of a sequence — which read the same lines: the 31 x 31 window of a closing
+// pair's 2-loops, the product columns — meet in no L2.  Flag bit 2: both roles' x ranges are
+// padded to multiples of 64 (so that x mod 8 IS the XCD whatever the sequence) and x is dealt so
+// that 8 workgroups in a row, 32 rows, land on one XCD, the XCDs rotated by sequence (short
+// sequences fill only the first runs: without the rotation those would always be XCD 0's).
+__device__ __forceinline__ uint32_t xcd_chunk(uint32_t x, uint32_t y) {
+  const uint32_t c = x & 7u, k = x >> 3;
+  return ((k & ~7u) + ((c + y) & 7u)) * 8u + (k & 7u);
+}
+__device__ __forceinline__ uint32_t role_block(const Ahead& ah) {
+  uint32_t bx = blockIdx.x;
+  if (ah.flags & 4u)
+    bx = bx < ah.main_blocks ? xcd_chunk(bx, blockIdx.y) : ah.main_blocks + xcd_chunk(bx - ah.main_blocks, blockIdx.y);
+  return bx;
+}
 
 // The <= 496 (a, b) pairs with a + b <= 30 (src/mccaskill_algo.rs:306-315) in 512 slots: slot
 // row r < 15 holds the 31 - r pairs of a = r followed by the r + 1 pairs of a = 30 - r; row 15
@@ -364,7 +382,10 @@ __global__ void __launch_bounds__(256) k_tree_init(TreeBatch b, int contra, int 
     // FoldSums::new (src/mccaskill_algo.rs:213-226): every sparse / dense sum starts absent
     // (the statics CS4 / IN4 / ACCS are read only where MBC says "may pair": any finite filler)
     const size_t total = static_cast<size_t>(T_COUNT) * sd.msz;
-    for (size_t x = t0; x < total; x += stride) base[x] = (x / sd.msz) >= T_ACCS ? 0.f : kNegInf;
+    for (size_t x = t0; x < total; x += stride) {
+      const size_t mi = x / sd.msz;
+      base[x] = (mi >= T_ACCS && mi < T_QB_D) ? 0.f : kNegInf;
+    }
     float* out = b.out + sd.out_off;
     const size_t olen = static_cast<size_t>(sd.n) * (sd.n + 1u) / 2u;
     for (size_t x = t0; x < olen; x += stride) out[x] = kNegInf;
@@ -493,15 +514,18 @@ __global__ void __launch_bounds__(256) k_tree_static(TreeBatch b) {
     reinterpret_cast<float4*>(q.m[T_IN4])[o] = in4;
     // the three nearest explicit 2-loops this pair closes (slots (0,0) (0,1) (1,0): kNear), so
     // that the sweep's launches find their scores with the cell's other operands
-    float nr[3] = {0.f, 0.f, 0.f};
-    for (uint32_t t = 0; t < kNear; t++) {
+    // (all of them where the lane-per-cell sweeps run: no scorer and no base windows in those)
+    float nr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const uint32_t nsl = b.lane ? Special<CONTRA>::N : kNear;
+    for (uint32_t t = 0; t < nsl; t++) {
       uint32_t a, bb;
       Special<CONTRA>::slot(t, a, bb);
       if (a + bb + 3u <= d)
         nr[t] = TModel<CONTRA>::twoloop(b, a, bb, si, sj, s[i + 1], s[i + 2], s[j - 1], s[j - 2], s[i + 1 + a],
                                         s[j - 1 - bb], s[j - bb], s[i + a]);
     }
-    reinterpret_cast<float4*>(q.m[T_NEAR4])[o] = make_float4(nr[0], nr[1], nr[2], 0.f);
+    reinterpret_cast<float4*>(q.m[T_NEAR4])[o] = make_float4(nr[0], nr[1], nr[2], nr[3]);
+    if (b.lane && Special<CONTRA>::N > 4) reinterpret_cast<float4*>(q.m[T_NEAR8])[o] = make_float4(nr[4], nr[5], nr[6], 0.f);
   }
 }
 
@@ -978,7 +1002,8 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(float* h
 #endif
   const TSeq q = load_tseq_hot(b, blockIdx.y, hbase, hmsz, hn, hld, use_one);
   const uint32_t n = q.n, ld = q.ld;
-  if (blockIdx.x >= ah.main_blocks) {
+  const uint32_t bx = role_block(ah);
+  if (bx >= ah.main_blocks) {
     // ---- the NEXT launch's closing-pair blocks, far part (see Ahead): one wave per row i takes
     // the cells (i, i+nd0) and (i, i+nd0+1); nothing here depends on this launch's cells
 #ifdef RNAMC_DEBUG_KNOBS
@@ -988,15 +1013,15 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(float* h
     __builtin_amdgcn_s_setprio(1);
     const bool split = (ah.flags & 2u) != 0u;
     const uint32_t wid = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
-        static_cast<int>((blockIdx.x - ah.main_blocks) * (BLOCK / 64) + threadIdx.x / 64)));
+        static_cast<int>((bx - ah.main_blocks) * (BLOCK / 64) + threadIdx.x / 64)));
     const uint32_t i = split ? wid >> 1 : wid;
     const bool doA = !split || (wid & 1u) == 0u, doB = !split || (wid & 1u) != 0u;
     const uint32_t lane = threadIdx.x & 63u;
     const size_t row_i = static_cast<size_t>(i) * ld;
-    const uint64_t wi = load_win64(q.pk, static_cast<int>(i));
     // (both cells' uniform operands in one round trip; a cell past the row's end reads the pad)
     const uint32_t j0 = i + ah.nd0;
     if (j0 >= n) return;
+    const uint64_t wi = load_win64(q.pk, static_cast<int>(i));
     const bool two = doB && ah.nd_count > 1u && j0 + 1u < n;
     const float mbcA = doA ? sload(q.m[T_MBC] + row_i + j0) : kNegInf;
     const float mbcB = two ? sload(q.m[T_MBC] + row_i + j0 + 1u) : kNegInf;
@@ -1017,7 +1042,7 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_inside2(float* h
   }
   // (wave-uniform: TPC is a multiple of 64)
   const uint32_t i = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
-      static_cast<int>(blockIdx.x * (BLOCK / TPC) + threadIdx.x / TPC)));
+      static_cast<int>(bx * (BLOCK / TPC) + threadIdx.x / TPC)));
   if (i + d >= n) return;
   // the launch's chain goes first at the issue ports: the mid-field kernel beside it (priority 0)
   // and the ahead waves (1) take what it leaves
@@ -1409,7 +1434,8 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(float* 
 #endif
   const TSeq q = load_tseq_hot(b, blockIdx.y, hbase, hmsz, hn, hld, use_one);
   const uint32_t n = q.n, ld = q.ld;
-  if (blockIdx.x >= ah.main_blocks) {
+  const uint32_t bx = role_block(ah);
+  if (bx >= ah.main_blocks) {
     // ---- the NEXT launch's enclosing 2-loops, far part (see Ahead): one wave per row i takes
     // the cells (i, i+nd0) and (i, i+nd0+1)
 #ifdef RNAMC_DEBUG_KNOBS
@@ -1418,14 +1444,14 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(float* 
     __builtin_amdgcn_s_setprio(1);
     const bool split = (ah.flags & 2u) != 0u;
     const uint32_t wid = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
-        static_cast<int>((blockIdx.x - ah.main_blocks) * (BLOCK / 64) + threadIdx.x / 64)));
+        static_cast<int>((bx - ah.main_blocks) * (BLOCK / 64) + threadIdx.x / 64)));
     const uint32_t i = split ? wid >> 1 : wid;
     const bool doA = !split || (wid & 1u) == 0u, doB = !split || (wid & 1u) != 0u;
     const uint32_t lane = threadIdx.x & 63u;
     const size_t row_i = static_cast<size_t>(i) * ld;
-    const uint64_t wi = load_win64(q.pk, static_cast<int>(i) - 31);
     const uint32_t j0 = i + ah.nd0;
     if (j0 >= n) return;
+    const uint64_t wi = load_win64(q.pk, static_cast<int>(i) - 31);
     const bool two = doB && ah.nd_count > 1u && j0 + 1u < n;
     const float qbA = doA ? sload(q.m[T_QB] + row_i + j0) : kNegInf;
     const float qbB = two ? sload(q.m[T_QB] + row_i + j0 + 1u) : kNegInf;
@@ -1445,7 +1471,7 @@ __global__ void __launch_bounds__(TPC < 256 ? 256 : TPC) k_tree_outside2(float* 
     return;
   }
   const uint32_t i = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
-      static_cast<int>(blockIdx.x * (BLOCK / TPC) + threadIdx.x / TPC)));
+      static_cast<int>(bx * (BLOCK / TPC) + threadIdx.x / TPC)));
   if (i + d >= n) return;
   __builtin_amdgcn_s_setprio(3);  // (as in the inside kernel)
   constexpr bool uf = UF;
@@ -2010,6 +2036,8 @@ void launch_tree_init(const TreeBatch& b, uint32_t nseq, uint32_t max_n, bool co
   hipLaunchKernelGGL(k_tree_init, dim3(gx, nseq, 1), dim3(256), 0, st, b, contra ? 1 : 0, what);
 }
 
+#include "rnamc_tree_lane.h"
+
 #define RNAMC_TREE_LAUNCH(K, C, T, U)                                                            \
   do {                                                                                            \
     const uint32_t gx_ = tree_grid<T>(cells, nd0, nd_count, max_n, nseq, pol, ah);                      \
@@ -2039,7 +2067,14 @@ static uint32_t tree_grid(uint32_t cells, uint32_t nd0, uint32_t nd_count, uint3
     ah.flags |= 2u;
     rows *= 2u;
   }
-  return ah.main_blocks + (rows + block / 64 - 1) / (block / 64);
+  uint32_t ahead_blocks = (rows + block / 64 - 1) / (block / 64);
+  // (xcd_chunk: one wave per cell pair, launches of at least 64 workgroups a sequence)
+  if (pol.xcd_rows && T == 64 && ah.main_blocks >= 64u) {
+    ah.flags |= 4u;
+    ah.main_blocks = (ah.main_blocks + 63u) & ~63u;
+    ahead_blocks = (ahead_blocks + 63u) & ~63u;
+  }
+  return ah.main_blocks + ahead_blocks;
 }
 static int tree_tpc(uint64_t cells, uint32_t terms, int64_t knob, const TreePolicy& pol) {
   if (knob == 64 || knob == 128 || knob == 256 || knob == 1024) return static_cast<int>(knob);

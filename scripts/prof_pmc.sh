@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 W="${1:-top256}"
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$W
 rm -rf $OUT && mkdir -p $OUT
-export CONTRA=0 GSIZES=1024
+export CONTRA=0 GSIZES=${GSIZES:-1024}
 i=0
 for SET in \
  "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
@@ -24,7 +24,9 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         kn = r["Kernel_Name"]
-        if "k_outside" in kn:
+        if "k_tree" in kn:
+            k = next(x for x in ("k_tree_inside", "k_tree_outside", "k_tree_mid", "k_tree_ext", "k_tree") if x in kn)
+        elif "k_outside" in kn:
             k = "k_outside_main" if ", 5>" in kn else "k_outside_tail" if ", 2>" in kn else "k_outside_small"
         elif "k_inside2" in kn:
             k = "k_inside2"
