@@ -81,6 +81,9 @@ struct rnamc_ctx {
   // tree_lane_min_nt nucleotides whose sweeps are banded), 2 always; bit 2 (value 4) set: inside sweep only
   int64_t tree_lane = 0;
   int64_t tree_lane_min_nt = 65536;
+  // lane-per-cell sweeps: a band's mid-field kernel runs in front of the band on the sweep's stream
+  // (threshold = the band's first / last diagonal) instead of a band ahead beside it
+  int64_t tree_mid_sync = 1;
   // tree mode, banded sweeps: the far part of a launch's 2-loop blocks is summed by extra
   // workgroups of the previous launch (rnamc_tree.hip, Ahead)
   int64_t tree_ahead = 1;
@@ -687,25 +690,35 @@ void build_tree_tabs(const rnamc_params& P, TreeTabs& T) {
       T.len[1][p] = (s0 + se) + f.interior_scores_len_cumulative[len - 2u];
     }
   }
-  // the generic slots by a + b (lane-per-cell sweeps); classes as slot_class of rnamc_tree.hip
+  // the generic slots by class, then a + b (lane-per-cell sweeps); classes as slot_class of rnamc_tree.hip
   for (int m = 0; m < 2; m++) {
     uint32_t cnt = 0;
-    for (uint32_t s = 0; s <= 30u; s++) {
-      for (uint32_t a = 0; a <= s; a++) {
-        const uint32_t b = s - a;
-        const bool special = m == 0 ? ((a + b <= 1u) || (a >= 1u && a <= 2u && b >= 1u && b <= 2u)) : (a <= 1u && b <= 1u);
-        if (special) continue;
-        const uint32_t p = a <= 15u ? a * 32u + b : (30u - a) * 32u + b + a + 1u;  // (probe_slot's inverse)
-        const uint32_t cls = ((a == 0u) != (b == 0u)) ? 0u
-                             : (a == 1u || b == 1u) ? 1u
-                             : ((a == 2u && b == 3u) || (a == 3u && b == 2u)) ? 2u : 3u;
-        T.gslot[m][cnt] = a | (b << 5) | (cls << 10);
-        T.glen[m][cnt] = T.len[m][p];
+    for (uint32_t c = 0; c < 4u; c++) {
+      T.gstart[m][c] = cnt;
+      uint32_t in_class = 0;
+      for (uint32_t s = 0; s <= 31u; s++) {
+        for (uint32_t a = 0; a <= s && s <= 30u; a++) {
+          const uint32_t b = s - a;
+          const bool special = m == 0 ? ((a + b <= 1u) || (a >= 1u && a <= 2u && b >= 1u && b <= 2u)) : (a <= 1u && b <= 1u);
+          if (special) continue;
+          const uint32_t cls = ((a == 0u) != (b == 0u)) ? 0u
+                               : (a == 1u || b == 1u) ? 1u
+                               : ((a == 2u && b == 3u) || (a == 3u && b == 2u)) ? 2u : 3u;
+          if (cls != c) continue;
+          const uint32_t p = a <= 15u ? a * 32u + b : (30u - a) * 32u + b + a + 1u;  // (probe_slot's inverse)
+          T.gslot[m][cnt] = a | (s << 8);
+          T.glen[m][cnt] = T.len[m][p];
+          cnt++;
+          in_class++;
+        }
+        T.gcount[m][c][s] = in_class;
+      }
+      while (cnt % 8u != 0u) {  // (never counted: keeps an eight-wide read inside the list)
+        T.gslot[m][cnt] = in_class ? T.gslot[m][cnt - 1] : 0u;
+        T.glen[m][cnt] = 0.f;
         cnt++;
       }
-      T.gcount[m][s] = cnt;
     }
-    T.gcount[m][31] = cnt;
   }
 }
 
@@ -938,6 +951,8 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
         launch_tree_ext(b, contra, dlo, dhi, gmax, active(dlo), c->bulk_stream);
         c->stats.launches_other++;
       };
+      const bool sync_in = (lane_mode & 1u) != 0u && c->tree_mid_sync != 0;
+      const bool sync_out = (lane_mode & 2u) != 0u && c->tree_mid_sync != 0;
       const bool ahead = c->tree_ahead != 0 && (c->tree_tpc == 0 || c->tree_tpc == 64);
       bool use_far = false;  // (the first launch of a sweep forms its blocks whole)
       uint32_t d = dmin_in;
@@ -951,13 +966,23 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
           if (rc) return rc;
           if (cur_band != ~0u) enqueue_ext(cur_band);
           cur_band = x;
-          if (x + 1 >= 3 && x + 1 < nb) {
-            rc = enqueue_mid(false, x + 1, x * band);
-            if (rc) return rc;
+          if (sync_in) {
+            // (a batch: the band's mid-field in front of the band, on the sweep's own stream — every
+            // diagonal below x * band is final, so the launches keep the terms of the band alone)
+            if (x >= 1) {
+              launch_tree_mid(b, false, x * band, std::min(gmax - 1, x * band + band - 1), x * band, gmax,
+                              active(x * band), c->tree_pol, st);
+              c->stats.launches_other++;
+            }
+          } else {
+            if (x + 1 >= 3 && x + 1 < nb) {
+              rc = enqueue_mid(false, x + 1, x * band);
+              if (rc) return rc;
+            }
+            if (x >= 3) HIPCHK(hipStreamWaitEvent(st, c->ev_b[x % ering], 0));
           }
-          if (x >= 3) HIPCHK(hipStreamWaitEvent(st, c->ev_b[x % ering], 0));
         }
-        const uint32_t thr = x >= 3 ? (x - 1) * band : 0u;
+        const uint32_t thr = sync_in ? x * band : (x >= 3 ? (x - 1) * band : 0u);
         if (lane_mode & 1u) {
           launch_tlane_inside(b, contra, d, gmax, active(d), thr, st);
           c->stats.launches_inside++;
@@ -995,15 +1020,30 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
         const uint32_t x = du / band;
         if (x != cur_band) {
           cur_band = x;
-          if (x >= 1 && (x + 1) * band < gmax) {  // band x-1 has a mid-field: thr = (x+1)*band <= gmax-1
-            rc = boundary(x);
-            if (rc) return rc;
-            rc = enqueue_mid(true, x - 1, (x + 1) * band);
-            if (rc) return rc;
+          if (sync_out) {
+            if ((x + 1) * band < gmax) {  // (operands of span >= (x+1)*band: everything above this band)
+              launch_tree_mid(b, true, x * band, std::min(gmax - 1, x * band + band - 1), (x + 1) * band, gmax,
+                              active(x * band), c->tree_pol, st);
+              c->stats.launches_other++;
+            }
+          } else {
+            if (x >= 1 && (x + 1) * band < gmax) {  // band x-1 has a mid-field: thr = (x+1)*band <= gmax-1
+              rc = boundary(x);
+              if (rc) return rc;
+              rc = enqueue_mid(true, x - 1, (x + 1) * band);
+              if (rc) return rc;
+            }
+            if ((x + 2) * band < gmax) HIPCHK(hipStreamWaitEvent(st, c->ev_b[x % ering], 0));
           }
-          if ((x + 2) * band < gmax) HIPCHK(hipStreamWaitEvent(st, c->ev_b[x % ering], 0));
         }
-        const uint32_t thr = (x + 2) * band < gmax ? (x + 2) * band : 0u;
+        const uint32_t thr = sync_out ? ((x + 1) * band < gmax ? (x + 1) * band : 0u)
+                                      : ((x + 2) * band < gmax ? (x + 2) * band : 0u);
+        if (lane_mode & 2u) {
+          launch_tlane_outside(b, contra, du, gmax, active(du), thr, st);
+          c->stats.launches_outside++;
+          dd--;
+          continue;
+        }
         const bool pair = du % 2u == 1u && du - 1 >= dmin_out;
         const uint32_t lower = pair ? du - 1 : du;
         // the next launch (below): a pair when its top is odd and both diagonals are swept
@@ -1290,6 +1330,8 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     c->tree_pol.ahead_waves = static_cast<uint64_t>(value);
   } else if (k == "tree_lane" && value >= 0 && value <= 7) {
     c->tree_lane = value;
+  } else if (k == "tree_mid_sync" && (value == 0 || value == 1)) {
+    c->tree_mid_sync = value;
   } else if (k == "tree_lane_min_nt" && value >= 0) {
     c->tree_lane_min_nt = value;
   } else if (k == "tree_xcd_rows" && (value == 0 || value == 1)) {

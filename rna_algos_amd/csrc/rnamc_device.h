@@ -118,11 +118,14 @@ enum TreeMat : int {
 // 1 CONTRAfold.
 struct TreeTabs {
   float len[2][512];
-  // lane-per-cell sweeps: the generic slots in order of a + b (a prefix of the list is what a cell of a
-  // given span can enclose): a | b << 5 | class << 10, the slot's length term, slots with a + b <= s
-  uint32_t gslot[2][512];
-  float glen[2][512];
-  uint32_t gcount[2][32];
+  // lane-per-cell sweeps: the generic slots by class, inside a class in order of a + b (a prefix of the
+  // class's list is what a cell of a given span can enclose): a | (a + b) << 8, the slot's length term;
+  // class c's list starts at gstart[c] (a multiple of 8; lists padded to multiples of 8 with their
+  // last slot), gcount[c][s] of its slots have a + b <= s
+  uint32_t gslot[2][544];
+  float glen[2][544];
+  uint32_t gstart[2][4];
+  uint32_t gcount[2][4][32];
 };
 struct TreeSeq {
   uint32_t n, ld;

@@ -411,8 +411,9 @@ __global__ void __launch_bounds__(256) k_tree_init(TreeBatch b, int contra, int 
     }
   } else {
     // the slots the outside sweep reuses (W, R, Pm2, SP, and PX4 in place of QbX4)
-    const int mats[8] = {T_ZRE, T_ZRM, T_QM, T_U, T_X4, T_X4 + 1, T_X4 + 2, T_X4 + 3};
-    for (int y = 0; y < 8; y++) {
+    // (lane-per-cell sweeps: R takes the diagonal-major Zr_mb's place too)
+    const int mats[9] = {T_ZRE, T_ZRM, T_QM, T_U, T_X4, T_X4 + 1, T_X4 + 2, T_X4 + 3, T_ZRM_D};
+    for (int y = 0; y < (b.lane ? 9 : 8); y++) {
       float* p = base + static_cast<size_t>(mats[y]) * sd.msz;
       for (size_t x = t0; x < sd.msz; x += stride) p[x] = kNegInf;
     }
