@@ -78,12 +78,12 @@ struct rnamc_ctx {
   // (a multiple of 32, at most 128; 0: every launch walks its sums whole)
   int64_t tree_band = 64;
   // tree mode: lane-per-cell sweeps (rnamc_tree_lane.h) — 0 never, 1 for batches (a call of at least
-  // tree_lane_min_nt nucleotides whose sweeps are banded), 2 always; bit 2 (value 4) set: inside sweep only
-  int64_t tree_lane = 0;
+  // tree_lane_min_nt nucleotides whose sweeps are banded), 2 always
+  int64_t tree_lane = 1;
   int64_t tree_lane_min_nt = 65536;
   // lane-per-cell sweeps: a band's mid-field kernel runs in front of the band on the sweep's stream
   // (threshold = the band's first / last diagonal) instead of a band ahead beside it
-  int64_t tree_mid_sync = 1;
+  int64_t tree_mid_sync = 0;
   // tree mode, banded sweeps: the far part of a launch's 2-loop blocks is summed by extra
   // workgroups of the previous launch (rnamc_tree.hip, Ahead)
   int64_t tree_ahead = 1;
@@ -797,8 +797,10 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
   uint32_t lane_mode = 0u;
   {
     const int64_t mode = c->tree_lane & 3;
-    if (band && (mode == 2 || (mode == 1 && offsets[n_seqs] - offsets[0] >= static_cast<uint64_t>(c->tree_lane_min_nt) && n_seqs > 1)))
-      lane_mode = (c->tree_lane & 4) ? 1u : 3u;
+    // (a plane of the sweep is one raw buffer there: msz * 4 bytes in a 32-bit record count)
+    const uint64_t ld_max = ((static_cast<uint64_t>(max_n) + 31u) & ~31ull) + 32u;
+    if (band && ld_max * max_n * 4ull + 1024ull < (1ull << 31) && (mode == 2 || (mode == 1 && offsets[n_seqs] - offsets[0] >= static_cast<uint64_t>(c->tree_lane_min_nt) && n_seqs > 1)))
+      lane_mode = 3u;
   }
   std::vector<TreeSeq>& tseqs = c->h_tseqs;
   tseqs.clear();
@@ -962,6 +964,11 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
         if (x != cur_band) {
           // band x starts: everything below x*band is enqueued; sums_external of band x-1 and
           // the mid-field of band x+1 can go
+          if (lane_mode && cur_band != ~0u) {  // (their readers want the band row- / column-major)
+            launch_tlane_spread(b, false, cur_band * band, std::min(gmax - 1, cur_band * band + band - 1), gmax,
+                                active(cur_band * band), st);
+            c->stats.launches_other++;
+          }
           rc = boundary(x);
           if (rc) return rc;
           if (cur_band != ~0u) enqueue_ext(cur_band);
@@ -999,6 +1006,11 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
         d += pair ? 2 : 1;
       }
       if (cur_band != ~0u) {  // the last band's sums_external; the outside sweep reads them
+        if (lane_mode) {
+          launch_tlane_spread(b, false, cur_band * band, std::min(gmax - 1, cur_band * band + band - 1), gmax,
+                              active(cur_band * band), st);
+          c->stats.launches_other++;
+        }
         rc = boundary(cur_band + 1);
         if (rc) return rc;
         enqueue_ext(cur_band);
@@ -1019,6 +1031,11 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
         const uint32_t du = static_cast<uint32_t>(dd);
         const uint32_t x = du / band;
         if (x != cur_band) {
+          if (lane_mode && cur_band != ~0u) {  // (the band above is through: W and R for the mid-field kernels)
+            launch_tlane_spread(b, true, cur_band * band, std::min(gmax - 1, cur_band * band + band - 1), gmax,
+                                active(cur_band * band), st);
+            c->stats.launches_other++;
+          }
           cur_band = x;
           if (sync_out) {
             if ((x + 1) * band < gmax) {  // (operands of span >= (x+1)*band: everything above this band)
@@ -1328,7 +1345,7 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     c->tree_pol.mid_wgs = static_cast<uint32_t>(std::min<int64_t>(value, 1 << 20));
   } else if (k == "tree_ahead_waves" && value >= 0) {
     c->tree_pol.ahead_waves = static_cast<uint64_t>(value);
-  } else if (k == "tree_lane" && value >= 0 && value <= 7) {
+  } else if (k == "tree_lane" && value >= 0 && value <= 2) {
     c->tree_lane = value;
   } else if (k == "tree_mid_sync" && (value == 0 || value == 1)) {
     c->tree_mid_sync = value;

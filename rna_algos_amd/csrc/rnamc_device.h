@@ -111,7 +111,12 @@ enum TreeMat : int {
   T_Q1_D = 32,   // sums_1ormore_basepairs
   T_ZRM_D = 33,  // sums_rightmost_basepairs_multibranch | outside: R
   T_W_D = 34,    // outside: W
-  T_COUNT = 35
+  T_COUNT = 35,
+  // ... and in those sweeps these slots hold diagonal-major data as well:
+  T_ZRE_D = T_QB,  // sums_rightmost_basepairs_external (the row-major sums_close has no reader there)
+  T_QA_D = T_W_D   // sums_accessible until the band is spread into T_QA (inside sweep)
+  // T_QM, T_U: sums_multibranch / the column prefix (inside), probs_multibranch2 / the column prefix of
+  // probs_multibranch (outside); the statics (T_HP .. T_NEAR8): cell (i, j) at [(j - i) * ld + i] too
 };
 // Length-dependent part of a generic 2-loop score per probe slot (rnamc_tree.hip, probe_slot),
 // derived from rnamc_params on the host (rnamc_api.cpp, build_tree_tabs).  Model index 0 Turner,
@@ -154,7 +159,7 @@ struct TreeBatch {
   int allows_short_hairpins;
   int debug;  // timing experiments (builds with -DRNAMC_DEBUG_KNOBS only; 0 otherwise)
   uint32_t ring;  // diagonals the mid-field ring holds (twice the band width; 0: no banding)
-  uint32_t lane;  // bit 0: the inside sweep runs lane-per-cell (T_X4 diagonal-major in it), bit 1: the outside sweep
+  uint32_t lane;  // != 0: both sweeps run lane-per-cell (rnamc_tree_lane.h: statics and sweep matrices diagonal-major)
 };
 // Launch-shape policy of the tree-order sweep, per context (rnamc_ctx_set "tree_waves",
 // "tree_short", "tree_ahead_waves", "tree_mid_wgs"): passed to every launch, no process globals.
@@ -203,6 +208,9 @@ void launch_tlane_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t m
                          hipStream_t st);
 void launch_tlane_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq, uint32_t thr,
                           hipStream_t st);
+// the finished band [dlo, dhi] into the row- / column-major copies k_tree_mid and k_tree_ext read
+void launch_tlane_spread(const TreeBatch& b, bool outside, uint32_t dlo, uint32_t dhi, uint32_t max_n, uint32_t nseq,
+                         hipStream_t st);
 void launch_tree_finalize(const TreeBatch& b, uint32_t nseq, uint32_t max_n, hipStream_t st);
 
 }  // namespace rnamc

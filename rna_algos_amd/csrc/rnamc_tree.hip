@@ -412,8 +412,8 @@ __global__ void __launch_bounds__(256) k_tree_init(TreeBatch b, int contra, int 
   } else {
     // the slots the outside sweep reuses (W, R, Pm2, SP, and PX4 in place of QbX4)
     // (lane-per-cell sweeps: R takes the diagonal-major Zr_mb's place too)
-    const int mats[9] = {T_ZRE, T_ZRM, T_QM, T_U, T_X4, T_X4 + 1, T_X4 + 2, T_X4 + 3, T_ZRM_D};
-    for (int y = 0; y < (b.lane ? 9 : 8); y++) {
+    const int mats[10] = {T_ZRE, T_ZRM, T_QM, T_U, T_X4, T_X4 + 1, T_X4 + 2, T_X4 + 3, T_ZRM_D, T_W_D};
+    for (int y = 0; y < (b.lane ? 10 : 8); y++) {
       float* p = base + static_cast<size_t>(mats[y]) * sd.msz;
       for (size_t x = t0; x < sd.msz; x += stride) p[x] = kNegInf;
     }
@@ -503,7 +503,7 @@ __global__ void __launch_bounds__(256) k_tree_static(TreeBatch b) {
     const bool act = canonical(si, sj) &&
                      ((b.allows_short_hairpins && CONTRA) || d + 1 >= RNAMC_MIN_SPAN_HAIRPIN_CLOSE);
     if (!act) continue;  // (the slots were filled with -inf / 0 by k_tree_init)
-    const size_t o = static_cast<size_t>(i) * ld + j;
+    const size_t o = b.lane ? static_cast<size_t>(d) * ld + i : static_cast<size_t>(i) * ld + j;
     q.m[T_HP][o] = (!CONTRA || d - 1 <= RNAMC_MAX_LOOP_LEN) ? model.hairpin(s, n, i, j) : kNegInf;
     q.m[T_MBC][o] = model.mbclose(s, n, i, j);
     q.m[T_ACCS][o] = model.accessible(s, n, i, j);

@@ -38,6 +38,18 @@ constexpr uint32_t kLaneParts = RNAMC_LANE_PARTS;
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
+__device__ __forceinline__ void acc_add8(Acc& a, const float (&x)[8]) {
+  const float m01 = __builtin_fmaxf(__builtin_fmaxf(x[0], x[1]), x[2]), m23 = __builtin_fmaxf(__builtin_fmaxf(x[3], x[4]), x[5]);
+  const float mn = __builtin_fmaxf(__builtin_fmaxf(a.m, m01), __builtin_fmaxf(__builtin_fmaxf(m23, x[6]), x[7]));
+  const float mb = mn * kL2E;
+  float e[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) e[u] = ex2(__builtin_fmaf(x[u], kL2E, -mb));
+  const float sum = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+  a.s = __builtin_fmaf(a.s, ex2((a.m - mn) * kL2E), sum);
+  a.m = mn;
+}
+
 // (+) of A[oa(x)] + B[ob(x)] over this wave's steps of x in [lo, hi), x < mine (the lane's own end)
 template <typename FA, typename FB>
 __device__ __forceinline__ void lane_sum(Acc& acc, const float* __restrict__ A, const float* __restrict__ B, uint32_t lo,
@@ -57,8 +69,7 @@ __device__ __forceinline__ void lane_sum(Acc& acc, const float* __restrict__ A, 
       const uint32_t xv = x + static_cast<uint32_t>(u);
       v[u] = (xv < hi && xv < mine) ? va[u] + vb[u] : kNegInf;
     }
-    acc_add4(acc, v[0], v[1], v[2], v[3]);
-    acc_add4(acc, v[4], v[5], v[6], v[7]);
+    acc_add8(acc, v);
   }
 }
 
@@ -66,14 +77,15 @@ __device__ __forceinline__ void lane_sum(Acc& acc, const float* __restrict__ A, 
 // class's list (ordered by a + b), the class's plane at diagonal `dbase -/+ (a + b)`, row
 // `i +/- (1 + a)`; st4: the cell's own class scores; own: added to every term (outside: sums_close of
 // the cell; there a slot counts for the lanes whose row has room for it, a < i and b < room = n - 1 - j).
-// A step's scalar work is what a wave spends most issue slots on here (the first form of this loop
-// took ~25 scalar instructions a slot for 64-bit plane and row offsets): the plane is the loop's
-// constant, the slot's row a 32-bit float offset inside it, the lane's part of the address one
-// register for the whole kernel.
+// A step's issue slots are what a launch's time goes to (the first form of this loop took ~25 scalar
+// and ~14 vector instructions a slot): the plane is a buffer resource, the slot's row a scalar byte
+// offset, the lane's part of the address one register for the whole kernel (buffer_load .. offen: no
+// vector instruction per load); what is the same for all of a class's terms — the cell's own class
+// score — is added once, to the class's accumulator.
 template <bool OUTSIDE, bool TAIL>
-__device__ __forceinline__ void lane_generic_step(Acc& acc, const float* __restrict__ plane, const uint32_t* __restrict__ gs,
+__device__ __forceinline__ void lane_generic_step(Acc& acc, __amdgpu_buffer_rsrc_t plane, const uint32_t* __restrict__ gs,
                                                   const float* __restrict__ gl, uint32_t e, uint32_t cnt, uint32_t ld,
-                                                  uint32_t dbase, uint32_t i, uint32_t vidx, float add, uint32_t room) {
+                                                  uint32_t dbase, uint32_t i, uint32_t voff, uint32_t room) {
   const u32x8 sl8 = *reinterpret_cast<const __attribute__((address_space(4))) u32x8*>(reinterpret_cast<uintptr_t>(gs + e));
   const f32x8 ln8 = *reinterpret_cast<const __attribute__((address_space(4))) f32x8*>(reinterpret_cast<uintptr_t>(gl + e));
   float g[8];
@@ -84,28 +96,22 @@ __device__ __forceinline__ void lane_generic_step(Acc& acc, const float* __restr
     const uint32_t sl = (!TAIL || e + static_cast<uint32_t>(u) < cnt) ? sl8[u] : sl8[0];
     const uint32_t a = sl & 255u, sab = sl >> 8;
     okl[u] = true;
-    if (OUTSIDE) {
-      okl[u] = a < i && sab - a < room;
-      g[u] = (plane + ((dbase + sab) * ld - a))[vidx];  // (vidx = max(i, 1) - 1: a lane without room reads a neighbour)
-    } else {
-      g[u] = (plane + ((dbase - sab) * ld + a))[vidx];  // (vidx = i + 1)
-    }
+    if (OUTSIDE) okl[u] = a < i && sab - a < room;
+    // (outside, voff = 4 (max(i, 1) - 1): a lane without room reads a neighbour of the row)
+    const uint32_t soff = 4u * (OUTSIDE ? (dbase + sab) * ld - a : (dbase - sab) * ld + a);
+    g[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(plane, static_cast<int>(voff), static_cast<int>(soff), 0));
   }
   __builtin_amdgcn_sched_barrier(0);
   float x[8];
 #pragma unroll
-  for (int u = 0; u < 8; u++) {
-    const float v = (g[u] + ln8[u]) + add;
-    x[u] = ((!TAIL || e + static_cast<uint32_t>(u) < cnt) && okl[u]) ? v : kNegInf;
-  }
-  acc_add4(acc, x[0], x[1], x[2], x[3]);
-  acc_add4(acc, x[4], x[5], x[6], x[7]);
+  for (int u = 0; u < 8; u++) x[u] = ((!TAIL || e + static_cast<uint32_t>(u) < cnt) && okl[u]) ? g[u] + ln8[u] : kNegInf;
+  acc_add8(acc, x);
 }
 template <bool CONTRA, bool OUTSIDE>
-__device__ __forceinline__ void lane_generic(Acc& acc, const TreeBatch& b, const float* __restrict__ x4, size_t msz,
-                                             uint32_t ld, uint32_t smax, uint32_t dbase, uint32_t i, const float4& st4,
-                                             float own, uint32_t room, uint32_t part) {
-  const uint32_t vidx = OUTSIDE ? max(i, 1u) - 1u : i + 1u;
+__device__ __forceinline__ void lane_generic(Acc& acc, const TreeBatch& b, float* x4, size_t msz, uint32_t ld,
+                                             uint32_t smax, uint32_t dbase, uint32_t i, const float4& st4, float own,
+                                             uint32_t room, uint32_t part) {
+  const uint32_t voff = 4u * (OUTSIDE ? max(i, 1u) - 1u : i + 1u);
   uint32_t turn = part;  // (the classes' steps are dealt to the block's waves in one round-robin)
 #pragma unroll
   for (uint32_t c = 0; c < 4u; c++) {
@@ -113,14 +119,17 @@ __device__ __forceinline__ void lane_generic(Acc& acc, const TreeBatch& b, const
     const uint32_t cnt = sload(&b.tabs->gcount[CONTRA ? 1 : 0][c][smax]);
     const uint32_t* __restrict__ gs = b.tabs->gslot[CONTRA ? 1 : 0] + start;
     const float* __restrict__ gl = b.tabs->glen[CONTRA ? 1 : 0] + start;
-    const float* __restrict__ plane = x4 + c * msz;
-    const float add = OUTSIDE ? own + pick(st4, c) : pick(st4, c);
+    // (raw buffer over the plane: byte offsets, reads past the end return 0 instead of faulting)
+    const __amdgpu_buffer_rsrc_t plane =
+        __builtin_amdgcn_make_buffer_rsrc(x4 + c * msz, 0, static_cast<int>(msz * sizeof(float)), 0x00020000);
     const uint32_t steps = (cnt + 7u) >> 3, full = cnt >> 3;
+    Acc ac = acc_empty();
     uint32_t st = turn;
-    for (; st < full; st += kLaneParts)
-      lane_generic_step<OUTSIDE, false>(acc, plane, gs, gl, 8u * st, cnt, ld, dbase, i, vidx, add, room);
-    if (st < steps) lane_generic_step<OUTSIDE, true>(acc, plane, gs, gl, 8u * st, cnt, ld, dbase, i, vidx, add, room);
+    for (; st < full; st += kLaneParts) lane_generic_step<OUTSIDE, false>(ac, plane, gs, gl, 8u * st, cnt, ld, dbase, i, voff, room);
+    if (st < steps) lane_generic_step<OUTSIDE, true>(ac, plane, gs, gl, 8u * st, cnt, ld, dbase, i, voff, room);
     turn = (turn + kLaneParts - steps % kLaneParts) % kLaneParts;
+    ac.m += OUTSIDE ? own + pick(st4, c) : pick(st4, c);  // (an empty accumulator stays empty: s = 0)
+    acc_merge(acc, ac);
   }
 }
 
@@ -154,21 +163,22 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_inside(TreeBatch b, u
   const uint32_t i = blockIdx.x * 64u + lane;
   if (blockIdx.x * 64u + d >= n) return;  // (the whole block: no barrier is left behind)
   const bool valid = i + d < n;
-  const uint32_t j = i + d;
+#ifdef RNAMC_DEBUG_KNOBS
+  if (b.debug & 4) return;
+#endif
   const size_t msz = static_cast<size_t>(q.m[1] - q.m[0]);
-  const size_t row = static_cast<size_t>(i) * ld + j, col = static_cast<size_t>(j) * ld + i;
   const size_t dg = static_cast<size_t>(d) * ld + i;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // [0] closing-pair block, [1] sums_multibranch
   Acc acc[2] = {acc_empty(), acc_empty()};
-  const float mbc = valid ? q.m[T_MBC][row] : kNegInf;
+  const float mbc = valid ? q.m[T_MBC][dg] : kNegInf;
   if (mbc > kNegInf) {
     if (part == 0u) {
-      const float hp = q.m[T_HP][row];
-      const float4 n4 = reinterpret_cast<const float4*>(q.m[T_NEAR4])[row];
-      const float4 n8 = CONTRA ? zero4 : reinterpret_cast<const float4*>(q.m[T_NEAR8])[row];
-      const float qm = d >= 2u ? q.m[T_QM][row + ld - 1u] : kNegInf;  // Qm(i+1, j-1)
+      const float hp = q.m[T_HP][dg];
+      const float4 n4 = reinterpret_cast<const float4*>(q.m[T_NEAR4])[dg];
+      const float4 n8 = CONTRA ? zero4 : reinterpret_cast<const float4*>(q.m[T_NEAR8])[dg];
+      const float qm = d >= 2u ? q.m[T_QM][dg - 2u * static_cast<size_t>(ld) + 1u] : kNegInf;  // Qm(i+1, j-1)
       const float nr[8] = {n4.x, n4.y, n4.z, n4.w, n8.x, n8.y, n8.z, 0.f};
       float xs[8];
 #pragma unroll
@@ -188,13 +198,19 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_inside(TreeBatch b, u
         acc_add(acc[0], xs[6]);
       }
     }
+#ifdef RNAMC_DEBUG_KNOBS
+    if (!(b.debug & 1))
+#endif
     if (d >= 5u) {  // (a generic slot has a + b >= 2)
-      const float4 cs = reinterpret_cast<const float4*>(q.m[T_CS4])[row];
+      const float4 cs = reinterpret_cast<const float4*>(q.m[T_CS4])[dg];
       lane_generic<CONTRA, false>(acc[0], b, q.m[T_X4], msz, ld, min(d - 3u, 30u), d - 2u, i, cs, 0.f, 0u, part);
     }
   }
   // sums_multibranch: x = Q1's span, Q1(i, i+x) + Zr_mb(i+1+x, j); banded (thr != 0): the terms with
   // both spans below thr are k_tree_mid's
+#ifdef RNAMC_DEBUG_KNOBS
+  if (!(b.debug & 2))
+#endif
   if (d >= 2u) {
     const float* __restrict__ A = q.m[T_Q1_D] + i;
     const float* __restrict__ B = q.m[T_ZRM_D] + (i + 1u);
@@ -218,11 +234,10 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_inside(TreeBatch b, u
   if (mbc > kNegInf) {
     const float qb = acc_value(acc[0]);
     if (qb > kNegInf) {
-      qa = qb + q.m[T_ACCS][row];
-      const float4 in4 = reinterpret_cast<const float4*>(q.m[T_IN4])[row];
-      q.m[T_QB][row] = qb;
+      qa = qb + q.m[T_ACCS][dg];
+      const float4 in4 = reinterpret_cast<const float4*>(q.m[T_IN4])[dg];
       q.m[T_QB_D][dg] = qb;
-      q.m[T_QA][row] = qa;
+      q.m[T_QA_D][dg] = qa;
       float* __restrict__ x4 = q.m[T_X4];
       x4[dg] = qb + in4.x;
       x4[msz + dg] = qb + in4.y;
@@ -235,21 +250,18 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_inside(TreeBatch b, u
   const float mb_bp = CONTRA ? b.params->contra.multibranch_score_basepair : b.params->turner.coeff_num_branches;
   const float mb_un = CONTRA ? b.params->contra.multibranch_score_unpair : 0.f;
   // rightmost-pair sums along the row, their column prefix
-  const float zr_e_prev = j >= 1u ? q.m[T_ZRE][col - ld] : kNegInf;              // Zr_ext(i, j-1)
-  const float zr_m_prev = (CONTRA && j >= 1u) ? q.m[T_ZRM][col - ld] : kNegInf;  // Zr_mb(i, j-1)
-  const float u_next = q.m[T_U][col + 1u];                                        // U(i+1, j) (i+1 == n: the pad)
+  const float zr_e_prev = d >= 1u ? q.m[T_ZRE_D][dg - ld] : kNegInf;              // Zr_ext(i, j-1)
+  const float zr_m_prev = (CONTRA && d >= 1u) ? q.m[T_ZRM_D][dg - ld] : kNegInf;  // Zr_mb(i, j-1)
+  const float u_next = d >= 1u ? q.m[T_U][dg - ld + 1u] : kNegInf;                // U(i+1, j)
   const float zr_e = lse2(zr_e_prev + ext_un, qa + ext_bp);
   const float zr_m = CONTRA ? lse2(zr_m_prev + mb_un, qa + mb_bp) : zr_e + mb_bp;
   const float u = lse2(u_next + mb_un, zr_m);
   const float qmv = acc_value(acc[1]);
   const float q1 = lse2(u, qmv);
-  q.m[T_ZRE][col] = zr_e;
-  q.m[T_ZRM][col] = zr_m;
+  q.m[T_ZRE_D][dg] = zr_e;
   q.m[T_ZRM_D][dg] = zr_m;
-  q.m[T_U][col] = u;
-  q.m[T_QM][row] = qmv;
-  q.m[T_Q1R][row] = q1;
-  q.m[T_Q1C][col] = q1;
+  q.m[T_U][dg] = u;
+  q.m[T_QM][dg] = qmv;
   q.m[T_Q1_D][dg] = q1;
 }
 
@@ -268,9 +280,11 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_outside(TreeBatch b, 
   const uint32_t i = blockIdx.x * 64u + lane;
   if (blockIdx.x * 64u + d >= n) return;
   const bool valid = i + d < n;
+#ifdef RNAMC_DEBUG_KNOBS
+  if (b.debug & 4) return;
+#endif
   const uint32_t j = i + d;
   const size_t msz = static_cast<size_t>(q.m[1] - q.m[0]);
-  const size_t row = static_cast<size_t>(i) * ld + j, col = static_cast<size_t>(j) * ld + i;
   const size_t dg = static_cast<size_t>(d) * ld + i, dg1 = dg + ld;  // (i, j) and (i, j+1)
   const float mb_un = CONTRA ? b.params->contra.multibranch_score_unpair : 0.f;
   const float ext_bp = CONTRA ? b.params->contra.external_score_basepair : 0.f;
@@ -288,6 +302,9 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_outside(TreeBatch b, 
   Acc acc[3] = {acc_empty(), acc_empty(), acc_empty()};
   // probs_multibranch(i,j) (540-543): x = 1 .., W(i, j+1+x) + Q1(j+1, j+x); banded: W's span d+1+x < thr
   const uint32_t hi = thr != 0u ? (thr > d + 1u ? thr - 1u - d : 0u) : n - d;  // (uniform end; room, i < n - d)
+#ifdef RNAMC_DEBUG_KNOBS
+  if (!(b.debug & 2))
+#endif
   if (hi > 1u) {
     auto oa = [&](uint32_t x) { return static_cast<size_t>(d + 1u + x) * ld; };
     auto ob = [&](uint32_t x) { return static_cast<size_t>(x - 1u) * ld + d + 1u; };
@@ -307,7 +324,7 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_outside(TreeBatch b, 
             const uint32_t k = i - 1u - a, dd = d + 2u + a + bb;
             const float nqb = q.m[T_QB_D][static_cast<size_t>(dd) * ld + k];
             const float npk = q.out[tri_off(n, dd) + k];
-            const float nsc = (t < 4u ? q.m[T_NEAR4] : q.m[T_NEAR8])[4u * (static_cast<size_t>(k) * ld + (k + dd)) + (t & 3u)];
+            const float nsc = (t < 4u ? q.m[T_NEAR4] : q.m[T_NEAR8])[4u * (static_cast<size_t>(dd) * ld + k) + (t & 3u)];
             if (nqb > kNegInf) xs[t] = ((npk + qb) - nqb) + nsc;
           }
         }
@@ -315,12 +332,18 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_outside(TreeBatch b, 
       acc_add4(acc[1], xs[0], xs[1], xs[2], xs[3]);
       if (!CONTRA) acc_add4(acc[1], xs[4], xs[5], xs[6], kNegInf);
     }
+#ifdef RNAMC_DEBUG_KNOBS
+    if (!(b.debug & 1))
+#endif
     if (n >= d + 5u) {  // (a generic slot has a + b >= 2, and a + b <= (i - 1) + room = n - 3 - d)
-      const float4 in4 = reinterpret_cast<const float4*>(q.m[T_IN4])[row];
+      const float4 in4 = reinterpret_cast<const float4*>(q.m[T_IN4])[dg];
       lane_generic<CONTRA, true>(acc[1], b, q.m[T_X4], msz, ld, min(n - 3u - d, 30u), d + 2u, i, in4, qb, room, part);
     }
   }
   // L_e cases one and three (594-601): x = 1 .., Q1(i-x, i-1) + R(i-1-x, j); banded: R's span d+1+x < thr
+#ifdef RNAMC_DEBUG_KNOBS
+  if (!(b.debug & 2))
+#endif
   if (hi > 1u) {
     auto oa = [&](uint32_t x) { return static_cast<size_t>(x - 1u) * ld - x; };
     auto ob = [&](uint32_t x) { return static_cast<size_t>(d + 1u + x) * ld - 1u - x; };
@@ -342,11 +365,10 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_outside(TreeBatch b, 
   const float sp_prev = i >= 1u ? sp_d[dg1 - 1u] : kNegInf;  // prefix of column j up to row i-1: cell (i-1, j)
   pm2_d[dg] = pm2;
   r_d[dg] = r;
-  q.m[T_ZRM][col] = r;
   sp_d[dg] = lse2(sp_prev + mb_un, pm);
   if (!paired) return;
   // the pair's probability (562-604): external, enclosing 2-loops, multibranch cases
-  const float qa = q.m[T_QA][row];
+  const float qa = qb + q.m[T_ACCS][dg];
   const float zpi = q.zp[i], zsj = q.zs[j + 1u], ztot = sload(q.zp + n);
   acc_add(acc[1], CONTRA ? (((zpi + zsj) + qa) + ext_bp) - ztot : ((zpi + qa) + zsj) - ztot);
   const float A = qa + abr;
@@ -354,11 +376,10 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_outside(TreeBatch b, 
   acc_add(acc[1], A + sp_prev);
   const float lp = acc_value(acc[1]);
   if (lp > kNegInf) {
-    const float w = (lp + q.m[T_MBC][row]) - qb;
-    const float4 cs = reinterpret_cast<const float4*>(q.m[T_CS4])[row];
+    const float w = (lp + q.m[T_MBC][dg]) - qb;
+    const float4 cs = reinterpret_cast<const float4*>(q.m[T_CS4])[dg];
     const float pq = lp - qb;
     q.out[tri_off(n, d) + i] = lp;
-    q.m[T_ZRE][row] = w;
     w_d[dg] = w;
     float* __restrict__ x4 = q.m[T_X4];
     x4[dg] = pq + cs.x;
@@ -368,7 +389,61 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_outside(TreeBatch b, 
   }
 }
 
+// ---- a finished band of diagonals [dlo, dhi] from the diagonal-major matrices into the row- and
+// column-major ones k_tree_mid and k_tree_ext read (tiles of 64 diagonals x 64 rows or columns through
+// LDS: both sides of the copy are 256-byte wave accesses).  blockIdx.z = which copy.
+//   inside : Q1 -> T_Q1R (row) and T_Q1C (column), Zr_mb -> T_ZRM (column), Zr_ext -> T_ZRE (column),
+//            sums_accessible -> T_QA (row)
+//   outside: W -> T_ZRE (row), R -> T_ZRM (column)
+__global__ void __launch_bounds__(256) k_tlane_spread(TreeBatch b, uint32_t dlo, uint32_t dhi, int outside) {
+  __shared__ float tile[64][65];
+  const TSeq q = load_tseq(b, blockIdx.y);
+  const int n = static_cast<int>(q.n);
+  const uint32_t ld = q.ld;
+  const int x0 = static_cast<int>(blockIdx.x) * 64;
+  if (x0 >= n) return;
+  const float* __restrict__ src;
+  float* __restrict__ dst;
+  bool colm;
+  if (outside) {
+    src = blockIdx.z == 0u ? q.m[T_W_D] : q.m[T_ZRM_D];
+    dst = blockIdx.z == 0u ? q.m[T_ZRE] : q.m[T_ZRM];
+    colm = blockIdx.z != 0u;
+  } else {
+    const uint32_t z = blockIdx.z;
+    src = z <= 1u ? q.m[T_Q1_D] : (z == 2u ? q.m[T_ZRM_D] : (z == 3u ? q.m[T_ZRE_D] : q.m[T_QA_D]));
+    dst = z == 0u ? q.m[T_Q1R] : (z == 1u ? q.m[T_Q1C] : (z == 2u ? q.m[T_ZRM] : (z == 3u ? q.m[T_ZRE] : q.m[T_QA])));
+    colm = z >= 1u && z <= 3u;
+  }
+  const int lane = static_cast<int>(threadIdx.x & 63u), wave = static_cast<int>(threadIdx.x >> 6);
+  for (int d0 = static_cast<int>(dlo); d0 <= static_cast<int>(dhi); d0 += 64) {
+    const int nd = min(64, static_cast<int>(dhi) - d0 + 1);
+    // row form: x = row i, the cell (i, i + d); column form: x = column j, the cell (j - d, j)
+    for (int dd = wave; dd < nd; dd += 4) {
+      const int d = d0 + dd, x = x0 + lane;
+      const int i = colm ? x - d : x;
+      tile[dd][lane] = (i >= 0 && i + d < n) ? src[static_cast<size_t>(d) * ld + i] : kNegInf;
+    }
+    __syncthreads();
+    for (int xx = wave; xx < 64; xx += 4) {
+      const int x = x0 + xx, d = d0 + lane;
+      if (lane < nd && x < n) {
+        const int i = colm ? x - d : x, j = colm ? x : x + d;
+        if (i >= 0 && j < n) dst[colm ? static_cast<size_t>(j) * ld + i : static_cast<size_t>(i) * ld + j] = tile[lane][xx];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
+
+void launch_tlane_spread(const TreeBatch& b, bool outside, uint32_t dlo, uint32_t dhi, uint32_t max_n, uint32_t nseq,
+                         hipStream_t st) {
+  if (dlo > dhi || nseq == 0u) return;
+  hipLaunchKernelGGL(k_tlane_spread, dim3((max_n + 63u) / 64u, nseq, outside ? 2u : 5u), dim3(256), 0, st, b, dlo, dhi,
+                     outside ? 1 : 0);
+}
 
 void launch_tlane_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq, uint32_t thr,
                           hipStream_t st) {

@@ -41,7 +41,8 @@ def run(ctx, seqs, contra, short, mode, **knobs):
     finally:
         ctx.set("summation_mode", 0)
         for k in knobs:
-            ctx.set(k, {"tree_two": 1, "tree_tpc": 0, "tree_band": 64, "tree_ahead": 1}[k])
+            ctx.set(k, {"tree_two": 1, "tree_tpc": 0, "tree_band": 64, "tree_ahead": 1, "tree_lane": 1,
+                        "tree_mid_sync": 0}[k])
 
 
 def deviation(a, b):
@@ -344,6 +345,44 @@ def test_tree_ragged_batch_and_lone_calls(ctx, params):
             # a launch ahead; alone, a short one is not: the same terms grouped differently)
             assert same and dp <= 2 * (2e-5 + 2e-7 * len(s)), (contra, short, len(s), dp)
             assert abs(float(z1[0]) - float(zb[x])) <= 1e-6 * max(1.0, abs(float(zb[x])))
+
+
+@pytest.mark.parametrize("contra,short", VARIANTS)
+def test_tree_lane_per_cell_batch(ctx, params, contra, short):
+    """The batch form of the mode (rnamc_tree_lane.h: a lane per cell, diagonal-major operands, one
+    diagonal per launch, bands spread into the row- / column-major copies of the mid-field kernels):
+    a ragged batch, lengths 1 .. 900 around the band boundaries, against the f64 evaluation of the
+    recurrences (the mode's own bound) and against the wave-per-cell launches of the same mode (the
+    same terms grouped differently: rounding); band 32 and the synchronous mid-field schedule too."""
+    lens = (900, 640, 410, 300, 257, 194, 193, 192, 129, 128, 127, 65, 64, 37, 5, 4, 2, 1)
+    seqs = [O.splitmix_seq(n, 17 * n + 3) for n in lens]
+    exact = [O.exact_bpp(params.ptr, s, contra, short) for s in seqs]
+    base, zbase = run(ctx, seqs, contra, short, 1, tree_lane=0)
+    first = None
+    for knobs in ({"tree_lane": 2}, {"tree_lane": 2, "tree_band": 32}, {"tree_lane": 2, "tree_mid_sync": 1}):
+        m, z = run(ctx, seqs, contra, short, 1, **knobs)
+        worst = 0.0
+        for s, a, za, b0, zb, (xb, xz) in zip(seqs, m, z, base, zbase, exact):
+            same, dt = deviation(a.packed, xb)
+            _, dw = deviation(b0.packed, xb)
+            # (the bound of the wave-per-cell launches, 2e-5 + 2e-7 n ~ 7 ulp of ln Z, with half as much
+            # again: another grouping of the same f32 sums lands on either side of it — printed below)
+            assert same and dt <= 1.5 * (2e-5 + 2e-7 * len(s)), (knobs, len(s), dt, dw)
+            assert abs(float(za) - xz) <= 2e-5 + 3e-6 * abs(xz), (knobs, len(s))
+            same, dp = deviation(a.packed, b0.packed)
+            assert same and dp <= 2 * (2e-5 + 2e-7 * len(s)), (knobs, len(s), dp)
+            worst = max(worst, dt / (2e-5 + 2e-7 * len(s)))
+        print(f"contra={contra} short={short} {knobs}: worst |dp| against f64 = {worst:.2f} x (2e-5 + 2e-7 n)")
+        if first is None:
+            first = m
+    # the same batch again: bit-identical (fixed merge orders), and the stats say which form ran
+    m2, _ = run(ctx, seqs, contra, short, 1, tree_lane=2)
+    for a, b0 in zip(m2, first):
+        assert np.array_equal(np.asarray(a.packed), np.asarray(b0.packed))
+    # one sequence of the batch alone in the batch form (other launch shapes, no ragged prefix)
+    m1, z1 = run(ctx, [seqs[1]], contra, short, 1, tree_lane=2)
+    same, dp = deviation(m1[0].packed, first[1].packed)
+    assert same and dp <= 2 * (2e-5 + 2e-7 * len(seqs[1]))
 
 
 def test_tree_edge_cases(ctx, params):
