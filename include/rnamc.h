@@ -247,7 +247,13 @@ int rnamc_ctx_set_params(rnamc_ctx* ctx, const rnamc_params* params);
  * terms take one wave per cell, default 256), "tree_ahead_waves" (waves up to which the ahead role
  * takes one wave per cell instead of one per row, default 16384), "tree_side_stream" (0: probe
  * whether the side stream runs beside the caller's stream and sweep unbanded if not — the default;
- * 1 / 2: take it as concurrent / serialised without probing).  Every knob is per context. */
+ * 1 / 2: take it as concurrent / serialised without probing), "tree_lane" (lane-per-cell sweeps,
+ * rnamc_tree_lane.h: 0 never, 1 for calls of several sequences and at least "tree_lane_min_nt"
+ * nucleotides — the default —, 2 always), "tree_mid_sync" (lane-per-cell sweeps: a band's mid-field
+ * kernel runs in front of the band on the sweep's own stream, default 1), "tree_mid_mx" (the
+ * mid-field products on the matrix cores, k_tree_mid_mx: exponentials per operand element, one
+ * v_mfma_f32_32x32x2_f32 multiply-add per term; default 1, 0 = the VALU form k_tree_mid).
+ * Every knob is per context. */
 int rnamc_ctx_set(rnamc_ctx* ctx, const char* name, int64_t value);
 
 /* mccaskill_algo over a batch (src/mccaskill_algo.rs:247-280 for each record, as

@@ -83,7 +83,7 @@ struct rnamc_ctx {
   int64_t tree_lane_min_nt = 65536;
   // lane-per-cell sweeps: a band's mid-field kernel runs in front of the band on the sweep's stream
   // (threshold = the band's first / last diagonal) instead of a band ahead beside it
-  int64_t tree_mid_sync = 0;
+  int64_t tree_mid_sync = 1;
   // tree mode, banded sweeps: the far part of a launch's 2-loop blocks is summed by extra
   // workgroups of the previous launch (rnamc_tree.hip, Ahead)
   int64_t tree_ahead = 1;
@@ -1345,6 +1345,8 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     c->tree_pol.mid_wgs = static_cast<uint32_t>(std::min<int64_t>(value, 1 << 20));
   } else if (k == "tree_ahead_waves" && value >= 0) {
     c->tree_pol.ahead_waves = static_cast<uint64_t>(value);
+  } else if (k == "tree_mid_mx" && (value == 0 || value == 1)) {
+    c->tree_pol.mid_mx = static_cast<uint32_t>(value);
   } else if (k == "tree_lane" && value >= 0 && value <= 2) {
     c->tree_lane = value;
   } else if (k == "tree_mid_sync" && (value == 0 || value == 1)) {

@@ -173,6 +173,8 @@ struct TreePolicy {
   uint32_t mid_wgs = 0;             // workgroups of a k_tree_mid launch; 0: by the longest sequence (256 below
                                     // 6 144 nt, 512 below 12 288, 1 024 beyond: from ~8 000 nt on the mid-field
                                     // products, not the launch chain, set the sweep's time: profiles/r04_tree_long.txt)
+  uint32_t mid_mx = 1;              // != 0: the mid-field products on the matrix cores (k_tree_mid_mx, rnamc_tree_mx.h:
+                                    // factors 2^(x log2 e - E) per operand element, v_mfma_f32_32x32x2_f32 per term)
 };
 // what = 0: everything before the inside sweep; 1: the four reused slots before the outside sweep
 void launch_tree_init(const TreeBatch& b, uint32_t nseq, uint32_t max_n, bool contra, int what,

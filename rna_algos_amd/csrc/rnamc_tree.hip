@@ -2038,6 +2038,7 @@ void launch_tree_init(const TreeBatch& b, uint32_t nseq, uint32_t max_n, bool co
 }
 
 #include "rnamc_tree_lane.h"
+#include "rnamc_tree_mx.h"
 
 #define RNAMC_TREE_LAUNCH(K, C, T, U)                                                            \
   do {                                                                                            \
@@ -2145,6 +2146,10 @@ void launch_tree_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t m
 void launch_tree_mid(const TreeBatch& b, bool outside, uint32_t dlo, uint32_t dhi, uint32_t thr,
                      uint32_t max_n, uint32_t nseq, const TreePolicy& pol, hipStream_t st) {
   if (dlo >= max_n || dhi < dlo || nseq == 0) return;
+  if (pol.mid_mx) {
+    launch_tree_mid_mx(b, outside, dlo, dhi, thr, max_n, nseq, st);
+    return;
+  }
   const uint32_t tiles_i = (max_n - dlo + kMidTI - 1) / kMidTI;
   const uint32_t tiles_z = ((dhi - dlo) / kMidTD + 1) * (outside ? 2u : 1u);
   const uint32_t wgs = pol.mid_wgs ? pol.mid_wgs : (max_n >= 12288u ? 1024u : (max_n >= 6144u ? 512u : 256u));
