@@ -791,7 +791,6 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
       c->side_probed = true;
       c->side_probed_for = st;
     }
-    if (c->side_verdict == 2) band = 0u;
   }
   // lane-per-cell sweeps: what a batch's fat launches want (a lone sequence keeps the wave-per-cell chain)
   uint32_t lane_mode = 0u;
@@ -801,6 +800,12 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
     const uint64_t ld_max = ((static_cast<uint64_t>(max_n) + 31u) & ~31ull) + 32u;
     if (band && ld_max * max_n * 4ull + 1024ull < (1ull << 31) && (mode == 2 || (mode == 1 && offsets[n_seqs] - offsets[0] >= static_cast<uint64_t>(c->tree_lane_min_nt) && n_seqs > 1)))
       lane_mode = 3u;
+  }
+  // (a serialised side stream: the unbanded sweep — unless the mid-field kernels run in front of their
+  // band on the sweep's own stream anyway; sums_external's walks then simply queue behind)
+  if (band && c->side_verdict == 2 && !(lane_mode && c->tree_mid_sync != 0)) {
+    band = 0u;
+    lane_mode = 0u;
   }
   std::vector<TreeSeq>& tseqs = c->h_tseqs;
   tseqs.clear();
@@ -917,6 +922,10 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
     launch_tree_init(b, nseq, gmax, contra, 0, st);
     launch_tree_static(b, contra, nseq, gmax, st);
     c->stats.launches_other += 2;
+    if (lane_mode) {
+      launch_tlane_list(b, gmax, nseq, st);
+      c->stats.launches_other++;
+    }
     const bool two = c->tree_two != 0;
     const uint32_t ering = static_cast<uint32_t>(c->ev_a.size());
     if (band) {
@@ -991,7 +1000,11 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
         }
         const uint32_t thr = sync_in ? x * band : (x >= 3 ? (x - 1) * band : 0u);
         if (lane_mode & 1u) {
-          launch_tlane_inside(b, contra, d, gmax, active(d), thr, st);
+          if (d == dmin_in) {  // (the first diagonal's closing-pair blocks)
+            launch_tlane_inside(b, contra, ~0u, d, gmax, active(d), 0u, st);
+            c->stats.launches_inside++;
+          }
+          launch_tlane_inside(b, contra, d, d + 1 < gmax ? d + 1 : ~0u, gmax, active(d), thr, st);
           c->stats.launches_inside++;
           d++;
           continue;
@@ -1056,7 +1069,13 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
         const uint32_t thr = sync_out ? ((x + 1) * band < gmax ? (x + 1) * band : 0u)
                                       : ((x + 2) * band < gmax ? (x + 2) * band : 0u);
         if (lane_mode & 2u) {
-          launch_tlane_outside(b, contra, du, gmax, active(du), thr, st);
+          if (du == gmax - 1) {  // (the top diagonal's enclosing 2-loops: none exist, the slots are written)
+            launch_tlane_outside(b, contra, ~0u, du, gmax, active(du), 0u, st);
+            c->stats.launches_outside++;
+          }
+          // (sequences that enter the sweep with the next launch need their 2-loop sums too)
+          const uint32_t dn = du > dmin_out ? du - 1 : ~0u;
+          launch_tlane_outside(b, contra, du, dn, gmax, active(dn != ~0u ? dn : du), thr, st);
           c->stats.launches_outside++;
           dd--;
           continue;

@@ -111,10 +111,14 @@ enum TreeMat : int {
   T_Q1_D = 32,   // sums_1ormore_basepairs
   T_ZRM_D = 33,  // sums_rightmost_basepairs_multibranch | outside: R
   T_W_D = 34,    // outside: W
-  T_COUNT = 35,
+  T_LIST = 35,   // u32 per entry: row d holds the rows i of the cells (i, i + d) that may pair, in order; the
+                 // count in the row's last entry (k_tlane_list; the 2-loop sums run a lane per LISTED cell)
+  T_COUNT = 36,
   // ... and in those sweeps these slots hold diagonal-major data as well:
   T_ZRE_D = T_QB,  // sums_rightmost_basepairs_external (the row-major sums_close has no reader there)
-  T_QA_D = T_W_D   // sums_accessible until the band is spread into T_QA (inside sweep)
+  T_QA_D = T_W_D,  // sums_accessible until the band is spread into T_QA (inside sweep)
+  T_P2_D = T_QB     // outside sweep: float2 per cell over the slots T_QB and T_QA (both free once the inside sweep
+                    // and its sums_external are through): {max, sum} of the pair's enclosing 2-loop terms
   // T_QM, T_U: sums_multibranch / the column prefix (inside), probs_multibranch2 / the column prefix of
   // probs_multibranch (outside); the statics (T_HP .. T_NEAR8): cell (i, j) at [(j - i) * ld + i] too
 };
@@ -206,10 +210,15 @@ int tree_side_stream_probe(hipStream_t main, hipStream_t side);
 // per-cell statics (hairpin / multibranch-close / accessible scores, 2-loop sides), once per group
 void launch_tree_static(const TreeBatch& b, bool contra, uint32_t nseq, uint32_t max_n, hipStream_t st);
 // lane-per-cell sweeps of a batch (rnamc_tree_lane.h): one diagonal per launch, a lane per cell
-void launch_tlane_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq, uint32_t thr,
-                         hipStream_t st);
-void launch_tlane_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq, uint32_t thr,
-                          hipStream_t st);
+// d: the diagonal whose cells take their sums and recurrences (a lane per row); d_b: the diagonal whose LISTED
+// cells (the ones that may pair) take their 2-loop sums in the same launch — one diagonal ahead of d in the
+// sweep's direction (either >= max_n: that role is absent)
+void launch_tlane_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t d_b, uint32_t max_n, uint32_t nseq,
+                         uint32_t thr, hipStream_t st);
+void launch_tlane_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t d_b, uint32_t max_n, uint32_t nseq,
+                          uint32_t thr, hipStream_t st);
+// the rows of the cells that may pair, diagonal by diagonal (after launch_tree_static)
+void launch_tlane_list(const TreeBatch& b, uint32_t max_n, uint32_t nseq, hipStream_t st);
 // the finished band [dlo, dhi] into the row- / column-major copies k_tree_mid and k_tree_ext read
 void launch_tlane_spread(const TreeBatch& b, bool outside, uint32_t dlo, uint32_t dhi, uint32_t max_n, uint32_t nseq,
                          hipStream_t st);

@@ -382,6 +382,15 @@ __global__ void __launch_bounds__(256) k_tree_init(TreeBatch b, int contra, int 
     // FoldSums::new (src/mccaskill_algo.rs:213-226): every sparse / dense sum starts absent
     // (the statics CS4 / IN4 / ACCS are read only where MBC says "may pair": any finite filler)
     const size_t total = static_cast<size_t>(T_COUNT) * sd.msz;
+    if (b.lane) {
+      // (lane-per-cell sweeps: k_tree_static writes MBC — the "may pair" flag — for every cell and the
+      // other statics where it is finite, their only readers; the lists are written whole: 20 of the 36 slots need no filler)
+      for (int mi = 0; mi < T_COUNT; mi++) {
+        if (mi == T_HP || mi == T_MBC || (mi >= T_ACCS && mi < T_QB_D) || mi == T_LIST) continue;
+        float* p = base + static_cast<size_t>(mi) * sd.msz;
+        for (size_t x = t0; x < sd.msz; x += stride) p[x] = kNegInf;
+      }
+    } else
     for (size_t x = t0; x < total; x += stride) {
       const size_t mi = x / sd.msz;
       base[x] = (mi >= T_ACCS && mi < T_QB_D) ? 0.f : kNegInf;
@@ -493,17 +502,36 @@ __global__ void __launch_bounds__(256) k_tree_static(TreeBatch b) {
   const uint32_t n = q.n, ld = q.ld;
   const uint8_t* __restrict__ s = q.s;
   const auto model = TModel<CONTRA>::make(b);
-  const uint64_t cells = static_cast<uint64_t>(n) * n;
+  // row-major statics: x = i n + j; diagonal-major (lane-per-cell sweeps): x = d ld + i, so that a wave's
+  // stores are consecutive, and MBC is written for EVERY cell (k_tree_init leaves the statics alone there)
+  const uint64_t cells = static_cast<uint64_t>(n) * (b.lane ? ld : n);
   for (uint64_t x = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; x < cells;
        x += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
-    const uint32_t i = static_cast<uint32_t>(x / n), j = static_cast<uint32_t>(x % n);
-    if (j <= i) continue;
+    uint32_t i, j;
+    if (b.lane) {
+      const uint32_t x32 = static_cast<uint32_t>(x);  // (n ld < 2^32 for every admitted n)
+      const uint32_t dd = x32 / ld;
+      i = x32 - dd * ld;
+      j = i + dd;
+      if (j >= n) continue;
+      if (dd == 0u) {
+        q.m[T_MBC][x32] = kNegInf;
+        continue;
+      }
+    } else {
+      i = static_cast<uint32_t>(x / n);
+      j = static_cast<uint32_t>(x % n);
+      if (j <= i) continue;
+    }
     const uint32_t d = j - i;
     const int si = s[i], sj = s[j];
     const bool act = canonical(si, sj) &&
                      ((b.allows_short_hairpins && CONTRA) || d + 1 >= RNAMC_MIN_SPAN_HAIRPIN_CLOSE);
-    if (!act) continue;  // (the slots were filled with -inf / 0 by k_tree_init)
     const size_t o = b.lane ? static_cast<size_t>(d) * ld + i : static_cast<size_t>(i) * ld + j;
+    if (!act) {  // (row-major: the slots were filled with -inf / 0 by k_tree_init)
+      if (b.lane) q.m[T_MBC][o] = kNegInf;
+      continue;
+    }
     q.m[T_HP][o] = (!CONTRA || d - 1 <= RNAMC_MAX_LOOP_LEN) ? model.hairpin(s, n, i, j) : kNegInf;
     q.m[T_MBC][o] = model.mbclose(s, n, i, j);
     q.m[T_ACCS][o] = model.accessible(s, n, i, j);
@@ -2088,7 +2116,7 @@ static int tree_tpc(uint64_t cells, uint32_t terms, int64_t knob, const TreePoli
 }
 
 void launch_tree_static(const TreeBatch& b, bool contra, uint32_t nseq, uint32_t max_n, hipStream_t st) {
-  const uint64_t cells = static_cast<uint64_t>(max_n) * max_n;
+  const uint64_t cells = static_cast<uint64_t>(max_n) * (b.lane ? ((max_n + 31u) & ~31u) + 32u : max_n);
   const uint32_t gx = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>((cells + 255) / 256, 4096)));
   if (contra)
     hipLaunchKernelGGL(k_tree_static<true>, dim3(gx, nseq, 1), dim3(256), 0, st, b);

@@ -152,33 +152,76 @@ __device__ __forceinline__ bool lane_join(Acc (&a)[NA], float2 (*lds)[kLaneParts
   return true;
 }
 
-// ---- inside sweep, diagonal d (src/mccaskill_algo.rs:296-351 / 430-486)
+// ---- the cells of a diagonal that may pair, in row order (k_tlane_list, once per group): the 2-loop sums
+// run over THESE — 6 of 16 base combinations are canonical, so a wave of 64 consecutive rows would walk
+// its ~490 slots with 24 lanes at work.  list[d * ld + c] = row of the c-th such cell of diagonal d, the
+// count in the row's last float (ld >= n + 32: never a list entry).  A wave then holds 64 LISTED cells
+// (their rows span ~170 floats: still whole lines) and every slot stays wave-uniform.
+__device__ __forceinline__ const uint32_t* lane_list(const TSeq& q, uint32_t d) {
+  return reinterpret_cast<const uint32_t*>(q.m[T_LIST]) + static_cast<size_t>(d) * q.ld;
+}
+__global__ void __launch_bounds__(256) k_tlane_list(TreeBatch b) {
+  __shared__ uint32_t wsum[4];
+  const TSeq q = load_tseq(b, blockIdx.y);
+  const uint32_t n = q.n, ld = q.ld, d = blockIdx.x;
+  if (d >= n) return;
+  uint32_t* __restrict__ out = reinterpret_cast<uint32_t*>(q.m[T_LIST]) + static_cast<size_t>(d) * ld;
+  const float* __restrict__ mbc = q.m[T_MBC] + static_cast<size_t>(d) * ld;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t base = 0;
+  for (uint32_t i0 = 0; i0 < n - d; i0 += 256u) {
+    const uint32_t i = i0 + threadIdx.x;
+    const bool on = i < n - d && mbc[i] > kNegInf;
+    const uint64_t bal = __builtin_amdgcn_ballot_w64(on);
+    const uint32_t before = static_cast<uint32_t>(__builtin_popcountll(bal & ((1ull << lane) - 1ull)));
+    if (lane == 0u) wsum[wave] = static_cast<uint32_t>(__builtin_popcountll(bal));
+    __syncthreads();
+    uint32_t off = base;
+    for (uint32_t w = 0; w < wave; w++) off += wsum[w];
+    if (on) out[off + before] = i;
+    base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0u) out[ld - 1u] = base;
+}
+
+// ---- inside sweep (src/mccaskill_algo.rs:296-351 / 430-486).  Two roles in one launch:
+//   blockIdx.x <  nb_a : the cells of diagonal d, a lane per row: sums_multibranch's in-band terms and the
+//                        row recurrences (the cell's sums_accessible was written a launch earlier);
+//   blockIdx.x >= nb_a : the closing-pair blocks of diagonal d_b = d + 1, a lane per LISTED cell: a 2-loop
+//                        (i,j) -> (i+1+a, j-1-b) and Qm(i+1, j-1) read diagonals <= d_b - 2, i.e. nothing
+//                        this launch writes.  (d_b >= n: no such role; nb_a = 0: that role alone.)
 template <bool CONTRA>
-__global__ void __launch_bounds__(64 * kLaneParts) k_tlane_inside(TreeBatch b, uint32_t d, uint32_t thr) {
-  __shared__ float2 red[2][kLaneParts][64];
+__global__ void __launch_bounds__(64 * kLaneParts) k_tlane_inside(TreeBatch b, uint32_t d, uint32_t thr, uint32_t nb_a,
+                                                                 uint32_t d_b) {
+  __shared__ float2 red[1][kLaneParts][64];
   const TSeq q = load_tseq(b, blockIdx.y);
   const uint32_t n = q.n, ld = q.ld;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t part = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)));
-  const uint32_t i = blockIdx.x * 64u + lane;
-  if (blockIdx.x * 64u + d >= n) return;  // (the whole block: no barrier is left behind)
-  const bool valid = i + d < n;
 #ifdef RNAMC_DEBUG_KNOBS
   if (b.debug & 4) return;
 #endif
   const size_t msz = static_cast<size_t>(q.m[1] - q.m[0]);
-  const size_t dg = static_cast<size_t>(d) * ld + i;
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  // [0] closing-pair block, [1] sums_multibranch
-  Acc acc[2] = {acc_empty(), acc_empty()};
-  const float mbc = valid ? q.m[T_MBC][dg] : kNegInf;
-  if (mbc > kNegInf) {
+  if (blockIdx.x >= nb_a) {
+    // ---- closing-pair blocks of the listed cells of diagonal d_b
+    const uint32_t db = d_b;
+    if (db >= n) return;
+    const uint32_t* __restrict__ list = lane_list(q, db);
+    const uint32_t cnt = sload(list + (ld - 1u));
+    const uint32_t c0 = (blockIdx.x - nb_a) * 64u;
+    if (c0 >= cnt) return;  // (the whole block)
+    const bool valid = c0 + lane < cnt;
+    const uint32_t i = valid ? list[c0 + lane] : list[c0];
+    const size_t dg = static_cast<size_t>(db) * ld + i;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    Acc acc[1] = {acc_empty()};
+    const float mbc = q.m[T_MBC][dg];  // (finite: a listed cell)
     if (part == 0u) {
       const float hp = q.m[T_HP][dg];
       const float4 n4 = reinterpret_cast<const float4*>(q.m[T_NEAR4])[dg];
       const float4 n8 = CONTRA ? zero4 : reinterpret_cast<const float4*>(q.m[T_NEAR8])[dg];
-      const float qm = d >= 2u ? q.m[T_QM][dg - 2u * static_cast<size_t>(ld) + 1u] : kNegInf;  // Qm(i+1, j-1)
+      const float qm = db >= 2u ? q.m[T_QM][dg - 2u * static_cast<size_t>(ld) + 1u] : kNegInf;  // Qm(i+1, j-1)
       const float nr[8] = {n4.x, n4.y, n4.z, n4.w, n8.x, n8.y, n8.z, 0.f};
       float xs[8];
 #pragma unroll
@@ -187,7 +230,7 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_inside(TreeBatch b, u
         if (t < Special<CONTRA>::N) {
           uint32_t a, bb;
           Special<CONTRA>::slot(t, a, bb);
-          if (a + bb + 3u <= d) xs[t] = q.m[T_QB_D][static_cast<size_t>(d - 2u - a - bb) * ld + (i + 1u + a)] + nr[t];
+          if (a + bb + 3u <= db) xs[t] = q.m[T_QB_D][static_cast<size_t>(db - 2u - a - bb) * ld + (i + 1u + a)] + nr[t];
         }
       }
       acc_add4(acc[0], hp, qm + mbc, xs[0], xs[1]);
@@ -201,11 +244,31 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_inside(TreeBatch b, u
 #ifdef RNAMC_DEBUG_KNOBS
     if (!(b.debug & 1))
 #endif
-    if (d >= 5u) {  // (a generic slot has a + b >= 2)
+    if (db >= 5u) {  // (a generic slot has a + b >= 2)
       const float4 cs = reinterpret_cast<const float4*>(q.m[T_CS4])[dg];
-      lane_generic<CONTRA, false>(acc[0], b, q.m[T_X4], msz, ld, min(d - 3u, 30u), d - 2u, i, cs, 0.f, 0u, part);
+      lane_generic<CONTRA, false>(acc[0], b, q.m[T_X4], msz, ld, min(db - 3u, 30u), db - 2u, i, cs, 0.f, 0u, part);
     }
+    if (!lane_join<1>(acc, red, lane, part)) return;
+    if (!valid) return;
+    const float qb = acc_value(acc[0]);
+    if (qb > kNegInf) {
+      const float4 in4 = reinterpret_cast<const float4*>(q.m[T_IN4])[dg];
+      q.m[T_QB_D][dg] = qb;
+      q.m[T_QA_D][dg] = qb + q.m[T_ACCS][dg];
+      float* __restrict__ x4 = q.m[T_X4];
+      x4[dg] = qb + in4.x;
+      x4[msz + dg] = qb + in4.y;
+      x4[2u * msz + dg] = qb + in4.z;
+      x4[3u * msz + dg] = qb + in4.w;
+    }
+    return;
   }
+  // ---- the cells of diagonal d
+  const uint32_t i = blockIdx.x * 64u + lane;
+  if (blockIdx.x * 64u + d >= n) return;  // (the whole block: no barrier is left behind)
+  const bool valid = i + d < n;
+  const size_t dg = static_cast<size_t>(d) * ld + i;
+  Acc acc[1] = {acc_empty()};
   // sums_multibranch: x = Q1's span, Q1(i, i+x) + Zr_mb(i+1+x, j); banded (thr != 0): the terms with
   // both spans below thr are k_tree_mid's
 #ifdef RNAMC_DEBUG_KNOBS
@@ -218,33 +281,19 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_inside(TreeBatch b, u
     auto ob = [&](uint32_t x) { return static_cast<size_t>(d - 1u - x) * ld + x; };
     const uint32_t mine = valid ? n : 0u;
     if (thr != 0u) {
-      lane_sum(acc[1], A, B, 0u, d - thr, mine, part, oa, ob);
-      lane_sum(acc[1], A, B, thr, d - 1u, mine, part, oa, ob);
+      lane_sum(acc[0], A, B, 0u, d - thr, mine, part, oa, ob);
+      lane_sum(acc[0], A, B, thr, d - 1u, mine, part, oa, ob);
     } else {
-      lane_sum(acc[1], A, B, 0u, d - 1u, mine, part, oa, ob);
+      lane_sum(acc[0], A, B, 0u, d - 1u, mine, part, oa, ob);
     }
   }
-  if (!lane_join<2>(acc, red, lane, part)) return;
+  if (!lane_join<1>(acc, red, lane, part)) return;
   if (!valid) return;
   if (thr != 0u && d >= 2u) {
     const float2 mm = q.mid[static_cast<size_t>(d % b.ring) * q.vec + i];
-    acc_merge(acc[1], Acc{mm.x, mm.y});
+    acc_merge(acc[0], Acc{mm.x, mm.y});
   }
-  float qa = kNegInf;
-  if (mbc > kNegInf) {
-    const float qb = acc_value(acc[0]);
-    if (qb > kNegInf) {
-      qa = qb + q.m[T_ACCS][dg];
-      const float4 in4 = reinterpret_cast<const float4*>(q.m[T_IN4])[dg];
-      q.m[T_QB_D][dg] = qb;
-      q.m[T_QA_D][dg] = qa;
-      float* __restrict__ x4 = q.m[T_X4];
-      x4[dg] = qb + in4.x;
-      x4[msz + dg] = qb + in4.y;
-      x4[2u * msz + dg] = qb + in4.z;
-      x4[3u * msz + dg] = qb + in4.w;
-    }
-  }
+  const float qa = q.m[T_QA_D][dg];  // (-inf unless the cell's closing-pair block was finite)
   const float ext_bp = CONTRA ? b.params->contra.external_score_basepair : 0.f;
   const float ext_un = CONTRA ? b.params->contra.external_score_unpair : 0.f;
   const float mb_bp = CONTRA ? b.params->contra.multibranch_score_basepair : b.params->turner.coeff_num_branches;
@@ -256,7 +305,7 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_inside(TreeBatch b, u
   const float zr_e = lse2(zr_e_prev + ext_un, qa + ext_bp);
   const float zr_m = CONTRA ? lse2(zr_m_prev + mb_un, qa + mb_bp) : zr_e + mb_bp;
   const float u = lse2(u_next + mb_un, zr_m);
-  const float qmv = acc_value(acc[1]);
+  const float qmv = acc_value(acc[0]);
   const float q1 = lse2(u, qmv);
   q.m[T_ZRE_D][dg] = zr_e;
   q.m[T_ZRM_D][dg] = zr_m;
@@ -265,26 +314,78 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_inside(TreeBatch b, u
   q.m[T_Q1_D][dg] = q1;
 }
 
-// ---- outside sweep, diagonal d, from the top (src/mccaskill_algo.rs:528-606 / 640-720).  In this sweep
+// ---- outside sweep, from the top (src/mccaskill_algo.rs:528-606 / 640-720).  In this sweep
 // T_QM holds probs_multibranch2 and T_U the column prefix of probs_multibranch DIAGONAL-major (their
 // only readers are this kernel's neighbours), T_X4 the planes PX4 = (log bpp - sums_close) + CS4[class],
 // T_ZRM_D R = Pm (+) Pm2, T_W_D W = (log bpp + mbclose) - sums_close; W row-major (T_ZRE) and R
-// column-major (T_ZRM) are kept for k_tree_mid.
+// column-major (T_ZRM) are kept for k_tree_mid.  Two roles as in the inside sweep:
+//   blockIdx.x <  nb_a : the cells of diagonal d (a lane per row): probs_multibranch, L_e, the recurrences,
+//                        the pair's probability — its 2-loop part (T_P2_D) was written a launch earlier;
+//   blockIdx.x >= nb_a : the enclosing 2-loops (562-593) of the listed cells of diagonal d_b = d - 1: they
+//                        read log bpp and PX4 of diagonals >= d_b + 2.  (d_b >= n: no such role.)
 template <bool CONTRA>
-__global__ void __launch_bounds__(64 * kLaneParts) k_tlane_outside(TreeBatch b, uint32_t d, uint32_t thr) {
-  __shared__ float2 red[3][kLaneParts][64];
+__global__ void __launch_bounds__(64 * kLaneParts) k_tlane_outside(TreeBatch b, uint32_t d, uint32_t thr, uint32_t nb_a,
+                                                                  uint32_t d_b) {
+  __shared__ float2 red[2][kLaneParts][64];
   const TSeq q = load_tseq(b, blockIdx.y);
   const uint32_t n = q.n, ld = q.ld;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t part = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)));
-  const uint32_t i = blockIdx.x * 64u + lane;
-  if (blockIdx.x * 64u + d >= n) return;
-  const bool valid = i + d < n;
 #ifdef RNAMC_DEBUG_KNOBS
   if (b.debug & 4) return;
 #endif
-  const uint32_t j = i + d;
   const size_t msz = static_cast<size_t>(q.m[1] - q.m[0]);
+  if (blockIdx.x >= nb_a) {
+    const uint32_t db = d_b;
+    if (db >= n) return;
+    const uint32_t* __restrict__ list = lane_list(q, db);
+    const uint32_t cnt = sload(list + (ld - 1u));
+    const uint32_t c0 = (blockIdx.x - nb_a) * 64u;
+    if (c0 >= cnt) return;
+    const bool valid = c0 + lane < cnt;
+    const uint32_t i = valid ? list[c0 + lane] : list[c0];
+    const uint32_t j = i + db;
+    const size_t dg = static_cast<size_t>(db) * ld + i;
+    const uint32_t room = n - 1u - j;  // bases right of j
+    const float qb = valid ? q.m[T_QB_D][dg] : kNegInf;
+    Acc acc[1] = {acc_empty()};
+    if (qb > kNegInf) {
+      if (part == 0u) {
+        float xs[8];
+#pragma unroll
+        for (uint32_t t = 0; t < 8u; t++) {
+          xs[t] = kNegInf;
+          if (t < Special<CONTRA>::N) {
+            uint32_t a, bb;
+            Special<CONTRA>::slot(t, a, bb);
+            if (a < i && bb < room) {
+              const uint32_t k = i - 1u - a, dd = db + 2u + a + bb;
+              const float nqb = q.m[T_QB_D][static_cast<size_t>(dd) * ld + k];
+              const float npk = q.out[tri_off(n, dd) + k];
+              const float nsc = (t < 4u ? q.m[T_NEAR4] : q.m[T_NEAR8])[4u * (static_cast<size_t>(dd) * ld + k) + (t & 3u)];
+              if (nqb > kNegInf) xs[t] = ((npk + qb) - nqb) + nsc;
+            }
+          }
+        }
+        acc_add4(acc[0], xs[0], xs[1], xs[2], xs[3]);
+        if (!CONTRA) acc_add4(acc[0], xs[4], xs[5], xs[6], kNegInf);
+      }
+#ifdef RNAMC_DEBUG_KNOBS
+      if (!(b.debug & 1))
+#endif
+      if (n >= db + 5u) {  // (a generic slot has a + b >= 2, and a + b <= (i - 1) + room = n - 3 - d)
+        const float4 in4 = reinterpret_cast<const float4*>(q.m[T_IN4])[dg];
+        lane_generic<CONTRA, true>(acc[0], b, q.m[T_X4], msz, ld, min(n - 3u - db, 30u), db + 2u, i, in4, qb, room, part);
+      }
+    }
+    if (!lane_join<1>(acc, red, lane, part)) return;
+    if (valid) reinterpret_cast<float2*>(q.m[T_P2_D])[dg] = make_float2(acc[0].m, acc[0].s);
+    return;
+  }
+  const uint32_t i = blockIdx.x * 64u + lane;
+  if (blockIdx.x * 64u + d >= n) return;
+  const bool valid = i + d < n;
+  const uint32_t j = i + d;
   const size_t dg = static_cast<size_t>(d) * ld + i, dg1 = dg + ld;  // (i, j) and (i, j+1)
   const float mb_un = CONTRA ? b.params->contra.multibranch_score_unpair : 0.f;
   const float ext_bp = CONTRA ? b.params->contra.external_score_basepair : 0.f;
@@ -298,8 +399,8 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_outside(TreeBatch b, 
   const float qb = valid ? q.m[T_QB_D][dg] : kNegInf;
   const bool paired = qb > kNegInf;
 
-  // [0] probs_multibranch, [1] the pair's 2-loop terms, [2] L_e cases one and three
-  Acc acc[3] = {acc_empty(), acc_empty(), acc_empty()};
+  // [0] probs_multibranch, [1] L_e cases one and three
+  Acc acc[2] = {acc_empty(), acc_empty()};
   // probs_multibranch(i,j) (540-543): x = 1 .., W(i, j+1+x) + Q1(j+1, j+x); banded: W's span d+1+x < thr
   const uint32_t hi = thr != 0u ? (thr > d + 1u ? thr - 1u - d : 0u) : n - d;  // (uniform end; room, i < n - d)
 #ifdef RNAMC_DEBUG_KNOBS
@@ -310,36 +411,6 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_outside(TreeBatch b, 
     auto ob = [&](uint32_t x) { return static_cast<size_t>(x - 1u) * ld + d + 1u; };
     lane_sum(acc[0], w_d + i, q1_d + i, 1u, hi, room, part, oa, ob);
   }
-  if (paired) {
-    // enclosing 2-loops (562-593)
-    if (part == 0u) {
-      float xs[8];
-#pragma unroll
-      for (uint32_t t = 0; t < 8u; t++) {
-        xs[t] = kNegInf;
-        if (t < Special<CONTRA>::N) {
-          uint32_t a, bb;
-          Special<CONTRA>::slot(t, a, bb);
-          if (a < i && bb < room) {
-            const uint32_t k = i - 1u - a, dd = d + 2u + a + bb;
-            const float nqb = q.m[T_QB_D][static_cast<size_t>(dd) * ld + k];
-            const float npk = q.out[tri_off(n, dd) + k];
-            const float nsc = (t < 4u ? q.m[T_NEAR4] : q.m[T_NEAR8])[4u * (static_cast<size_t>(dd) * ld + k) + (t & 3u)];
-            if (nqb > kNegInf) xs[t] = ((npk + qb) - nqb) + nsc;
-          }
-        }
-      }
-      acc_add4(acc[1], xs[0], xs[1], xs[2], xs[3]);
-      if (!CONTRA) acc_add4(acc[1], xs[4], xs[5], xs[6], kNegInf);
-    }
-#ifdef RNAMC_DEBUG_KNOBS
-    if (!(b.debug & 1))
-#endif
-    if (n >= d + 5u) {  // (a generic slot has a + b >= 2, and a + b <= (i - 1) + room = n - 3 - d)
-      const float4 in4 = reinterpret_cast<const float4*>(q.m[T_IN4])[dg];
-      lane_generic<CONTRA, true>(acc[1], b, q.m[T_X4], msz, ld, min(n - 3u - d, 30u), d + 2u, i, in4, qb, room, part);
-    }
-  }
   // L_e cases one and three (594-601): x = 1 .., Q1(i-x, i-1) + R(i-1-x, j); banded: R's span d+1+x < thr
 #ifdef RNAMC_DEBUG_KNOBS
   if (!(b.debug & 2))
@@ -347,15 +418,15 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_outside(TreeBatch b, 
   if (hi > 1u) {
     auto oa = [&](uint32_t x) { return static_cast<size_t>(x - 1u) * ld - x; };
     auto ob = [&](uint32_t x) { return static_cast<size_t>(d + 1u + x) * ld - 1u - x; };
-    lane_sum(acc[2], q1_d + i, r_d + i, 1u, hi, paired ? i : 0u, part, oa, ob);
+    lane_sum(acc[1], q1_d + i, r_d + i, 1u, hi, paired ? i : 0u, part, oa, ob);
   }
-  if (!lane_join<3>(acc, red, lane, part)) return;
+  if (!lane_join<2>(acc, red, lane, part)) return;
   if (!valid) return;
   if (thr != 0u) {
     const float2 m1 = q.mid[(static_cast<size_t>(b.ring) + d % b.ring) * q.vec + i];
     acc_merge(acc[0], Acc{m1.x, m1.y});
     const float2 m2 = q.mid[(2u * static_cast<size_t>(b.ring) + d % b.ring) * q.vec + i];
-    acc_merge(acc[2], Acc{m2.x, m2.y});
+    acc_merge(acc[1], Acc{m2.x, m2.y});
   }
   // probs_multibranch2(i,j) from the right neighbour (544-549), R, the column prefix
   const float pm2_next = room >= 1u ? pm2_d[dg1] : kNegInf, w_next = room >= 1u ? w_d[dg1] : kNegInf;
@@ -370,11 +441,13 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_outside(TreeBatch b, 
   // the pair's probability (562-604): external, enclosing 2-loops, multibranch cases
   const float qa = qb + q.m[T_ACCS][dg];
   const float zpi = q.zp[i], zsj = q.zs[j + 1u], ztot = sload(q.zp + n);
-  acc_add(acc[1], CONTRA ? (((zpi + zsj) + qa) + ext_bp) - ztot : ((zpi + qa) + zsj) - ztot);
+  const float2 p2 = reinterpret_cast<const float2*>(q.m[T_P2_D])[dg];
+  Acc pa = Acc{p2.x, p2.y};
+  acc_add(pa, CONTRA ? (((zpi + zsj) + qa) + ext_bp) - ztot : ((zpi + qa) + zsj) - ztot);
   const float A = qa + abr;
-  acc_add(acc[1], A + acc_value(acc[2]));
-  acc_add(acc[1], A + sp_prev);
-  const float lp = acc_value(acc[1]);
+  acc_add(pa, A + acc_value(acc[1]));
+  acc_add(pa, A + sp_prev);
+  const float lp = acc_value(pa);
   if (lp > kNegInf) {
     const float w = (lp + q.m[T_MBC][dg]) - qb;
     const float4 cs = reinterpret_cast<const float4*>(q.m[T_CS4])[dg];
@@ -445,20 +518,31 @@ void launch_tlane_spread(const TreeBatch& b, bool outside, uint32_t dlo, uint32_
                      outside ? 1 : 0);
 }
 
-void launch_tlane_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq, uint32_t thr,
-                          hipStream_t st) {
-  const uint32_t gx = (max_n - d + 63u) / 64u;
-  if (contra)
-    hipLaunchKernelGGL(k_tlane_outside<true>, dim3(gx, nseq, 1), dim3(64 * kLaneParts), 0, st, b, d, thr);
-  else
-    hipLaunchKernelGGL(k_tlane_outside<false>, dim3(gx, nseq, 1), dim3(64 * kLaneParts), 0, st, b, d, thr);
+void launch_tlane_list(const TreeBatch& b, uint32_t max_n, uint32_t nseq, hipStream_t st) {
+  if (nseq == 0u || max_n == 0u) return;
+  hipLaunchKernelGGL(k_tlane_list, dim3(max_n, nseq, 1), dim3(256), 0, st, b);
 }
 
-void launch_tlane_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t max_n, uint32_t nseq, uint32_t thr,
-                         hipStream_t st) {
-  const uint32_t gx = (max_n - d + 63u) / 64u;
+// d: the diagonal of the per-row role (>= max_n: none); d_b: the diagonal whose listed cells take their 2-loop
+// sums in this launch (>= max_n: none)
+void launch_tlane_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t d_b, uint32_t max_n, uint32_t nseq,
+                          uint32_t thr, hipStream_t st) {
+  const uint32_t nb_a = d < max_n ? (max_n - d + 63u) / 64u : 0u;
+  const uint32_t nb_b = d_b < max_n ? (max_n - d_b + 63u) / 64u : 0u;
+  if (nb_a + nb_b == 0u || nseq == 0u) return;
   if (contra)
-    hipLaunchKernelGGL(k_tlane_inside<true>, dim3(gx, nseq, 1), dim3(64 * kLaneParts), 0, st, b, d, thr);
+    hipLaunchKernelGGL(k_tlane_outside<true>, dim3(nb_a + nb_b, nseq, 1), dim3(64 * kLaneParts), 0, st, b, d, thr, nb_a, d_b);
   else
-    hipLaunchKernelGGL(k_tlane_inside<false>, dim3(gx, nseq, 1), dim3(64 * kLaneParts), 0, st, b, d, thr);
+    hipLaunchKernelGGL(k_tlane_outside<false>, dim3(nb_a + nb_b, nseq, 1), dim3(64 * kLaneParts), 0, st, b, d, thr, nb_a, d_b);
+}
+
+void launch_tlane_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t d_b, uint32_t max_n, uint32_t nseq,
+                         uint32_t thr, hipStream_t st) {
+  const uint32_t nb_a = d < max_n ? (max_n - d + 63u) / 64u : 0u;
+  const uint32_t nb_b = d_b < max_n ? (max_n - d_b + 63u) / 64u : 0u;
+  if (nb_a + nb_b == 0u || nseq == 0u) return;
+  if (contra)
+    hipLaunchKernelGGL(k_tlane_inside<true>, dim3(nb_a + nb_b, nseq, 1), dim3(64 * kLaneParts), 0, st, b, d, thr, nb_a, d_b);
+  else
+    hipLaunchKernelGGL(k_tlane_inside<false>, dim3(nb_a + nb_b, nseq, 1), dim3(64 * kLaneParts), 0, st, b, d, thr, nb_a, d_b);
 }

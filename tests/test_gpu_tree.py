@@ -42,7 +42,7 @@ def run(ctx, seqs, contra, short, mode, **knobs):
         ctx.set("summation_mode", 0)
         for k in knobs:
             ctx.set(k, {"tree_two": 1, "tree_tpc": 0, "tree_band": 64, "tree_ahead": 1, "tree_lane": 1,
-                        "tree_mid_sync": 0}[k])
+                        "tree_mid_sync": 1, "tree_mid_mx": 1}[k])
 
 
 def deviation(a, b):
@@ -353,13 +353,16 @@ def test_tree_lane_per_cell_batch(ctx, params, contra, short):
     diagonal per launch, bands spread into the row- / column-major copies of the mid-field kernels):
     a ragged batch, lengths 1 .. 900 around the band boundaries, against the f64 evaluation of the
     recurrences (the mode's own bound) and against the wave-per-cell launches of the same mode (the
-    same terms grouped differently: rounding); band 32 and the synchronous mid-field schedule too."""
+    same terms grouped differently: rounding); band 32, the mid-field kernels a band ahead on the side
+    stream instead of in front of the band, and the VALU form of the mid-field products instead of the
+    matrix-core form (rnamc_tree_mx.h) too."""
     lens = (900, 640, 410, 300, 257, 194, 193, 192, 129, 128, 127, 65, 64, 37, 5, 4, 2, 1)
     seqs = [O.splitmix_seq(n, 17 * n + 3) for n in lens]
     exact = [O.exact_bpp(params.ptr, s, contra, short) for s in seqs]
     base, zbase = run(ctx, seqs, contra, short, 1, tree_lane=0)
     first = None
-    for knobs in ({"tree_lane": 2}, {"tree_lane": 2, "tree_band": 32}, {"tree_lane": 2, "tree_mid_sync": 1}):
+    for knobs in ({"tree_lane": 2}, {"tree_lane": 2, "tree_band": 32}, {"tree_lane": 2, "tree_mid_sync": 0},
+                  {"tree_lane": 2, "tree_mid_mx": 0}):
         m, z = run(ctx, seqs, contra, short, 1, **knobs)
         worst = 0.0
         for s, a, za, b0, zb, (xb, xz) in zip(seqs, m, z, base, zbase, exact):
