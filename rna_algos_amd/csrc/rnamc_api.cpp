@@ -84,6 +84,9 @@ struct rnamc_ctx {
   // lane-per-cell sweeps: a band's mid-field kernel runs in front of the band on the sweep's stream
   // (threshold = the band's first / last diagonal) instead of a band ahead beside it
   int64_t tree_mid_sync = 1;
+  // lane-per-cell sweeps with the mid-field in front of its band: the band's width (the in-band terms are
+  // the lanes' own loops: narrower bands, fewer of them; the matrix-core mid-field takes the rest)
+  int64_t tree_lane_band = 32;
   // tree mode, banded sweeps: the far part of a launch's 2-loop blocks is summed by extra
   // workgroups of the previous launch (rnamc_tree.hip, Ahead)
   int64_t tree_ahead = 1;
@@ -99,6 +102,7 @@ struct rnamc_ctx {
   int64_t group_max_seqs = 8192;
   int64_t group_max_nt = 2ll << 20;  // a group holds ~2M nucleotides (or 64 GB of DP state)
   int64_t group_ws_bytes = 64ll << 30;
+  bool group_ws_user = false;  // the knob was set: the tree-order batch form takes it as given
   int64_t block_threads = 256;
   int64_t profile = 0;
   // dispatch order of the role blocks of a launch (measured: pair-probability chains first,
@@ -762,7 +766,7 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
     return (offsets[a + 1] - offsets[a]) > (offsets[b + 1] - offsets[b]);
   });
-  const uint64_t ws_cap_floats = static_cast<uint64_t>(std::max<int64_t>(c->group_ws_bytes, 1)) / 4;
+  uint64_t ws_cap_floats = static_cast<uint64_t>(std::max<int64_t>(c->group_ws_bytes, 1)) / 4;
   // banding needs two diagonals per launch aligned to even diagonals, 32-bit float offsets INSIDE
   // one matrix (true for every n <= RNAMC_MAX_SEQ_LEN: ld * n < 2^32), and sequences long enough
   // to have a banded diagonal at all
@@ -806,6 +810,22 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
   if (band && c->side_verdict == 2 && !(lane_mode && c->tree_mid_sync != 0)) {
     band = 0u;
     lane_mode = 0u;
+  }
+  if (lane_mode && c->tree_mid_sync != 0 && static_cast<uint32_t>(c->tree_lane_band) < band)
+    band = static_cast<uint32_t>(c->tree_lane_band);
+  if (lane_mode && !c->group_ws_user) {
+    // The batch form's launches cost ~8 us each whatever they hold, and a group's 36 n^2 floats per
+    // sequence are what limits its size: twice the default workspace where the device has the room
+    // (measured on a 1 000-sequence slice of the bench batch: 16 / 32 / 64 / 128 GB -> 1167 / 909 / 787 /
+    // 753 ms per pass).
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const uint64_t have = static_cast<uint64_t>(free_b) + c->ws_floats * 4ull;
+      const uint64_t margin = 24ull << 30;
+      if (have > (128ull << 30) + margin) ws_cap_floats = (128ull << 30) / 4;
+    } else {
+      (void)hipGetLastError();
+    }
   }
   std::vector<TreeSeq>& tseqs = c->h_tseqs;
   tseqs.clear();
@@ -1364,6 +1384,8 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     c->tree_pol.mid_wgs = static_cast<uint32_t>(std::min<int64_t>(value, 1 << 20));
   } else if (k == "tree_ahead_waves" && value >= 0) {
     c->tree_pol.ahead_waves = static_cast<uint64_t>(value);
+  } else if (k == "tree_lane_band" && value >= 32 && value <= 128 && value % 32 == 0) {
+    c->tree_lane_band = value;
   } else if (k == "tree_mid_mx" && (value == 0 || value == 1)) {
     c->tree_pol.mid_mx = static_cast<uint32_t>(value);
   } else if (k == "tree_lane" && value >= 0 && value <= 2) {
@@ -1388,6 +1410,7 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     c->group_max_nt = value;
   } else if (k == "group_ws_bytes" && value >= 4) {
     c->group_ws_bytes = value;
+    c->group_ws_user = true;
   } else if (k == "block_threads" && value >= 64 && value <= 256 && value % 64 == 0) {
     // (the sweep kernels are compiled with __launch_bounds__(256))
     c->block_threads = value;

@@ -85,23 +85,34 @@ __device__ __forceinline__ int mx_scale(float (&v)[16], uint32_t lane) {
   return has ? static_cast<int>(ef) - kMxBias : kMxNone;
 }
 
+// KS = 4: the workgroup's four waves share one tile (k slices, merged through LDS) — few tiles, long k ranges:
+// a lone sequence; KS = 1: a tile per wave, its whole k range in one software pipeline — a batch's thousands
+// of tiles, whose k ranges are a few chunks (one wave's first loads are the exposed part of a tile's time).
+template <int KS>
 __global__ void __launch_bounds__(64 * kMxWaves)
 k_tree_mid_mx(TreeBatch b, uint32_t dlo, uint32_t dhi, uint32_t thr, int outside, uint32_t nbi, uint32_t ntc) {
   __shared__ int ea_lds[kMxWaves][32];
-  __shared__ float2 red[kMxWaves][16][64];  // {exponent (as int bits), sum}
+  __shared__ float2 red[KS == 1 ? 1 : kMxWaves][16][64];  // {exponent (as int bits), sum}
   const TSeq q = load_tseq(b, blockIdx.y);
   const int n = static_cast<int>(q.n);
   const uint32_t ld = q.ld;
-  const uint32_t tc = blockIdx.x % ntc, rest = blockIdx.x / ntc;
-  const uint32_t bi = rest % nbi;
-  const int prod = outside ? 1 + static_cast<int>(rest / nbi) : 0;
-  const int i0 = 32 * static_cast<int>(bi), j0 = i0 + static_cast<int>(dlo) + 32 * static_cast<int>(tc);
-  const int dtop = min(static_cast<int>(dhi), n - 1);
-  // (uniform: no cell of the band in this tile)
-  if (j0 >= n || j0 - (i0 + 31) > dtop) return;
-  const int T = static_cast<int>(thr);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)));
+  // (Workgroups go to the 8 XCDs round-robin by id.  Dealing them so that tile neighbours — which share B
+  // columns — meet in one L2 was measured twice, whole eighths of the tile order per XCD and runs of four
+  // workgroups: 10-20 % SLOWER passes both times, profiles/r04_tree_batch_route.txt; the plain order stays.)
+  const uint32_t bx = blockIdx.x;
+  const uint32_t tile = KS == 1 ? bx * kMxWaves + wave : bx;
+  if (KS != 1 && tile >= nbi * ntc * (outside ? 2u : 1u)) return;  // (padding; uniform)
+  const uint32_t tc = tile % ntc, rest = tile / ntc;
+  const uint32_t bi = rest % nbi;
+  const int prod = outside ? 1 + static_cast<int>(rest / nbi) : 0;
+  if (KS == 1 && rest / nbi >= (outside ? 2u : 1u)) return;  // (the last workgroup's spare waves)
+  const int i0 = 32 * static_cast<int>(bi), j0 = i0 + static_cast<int>(dlo) + 32 * static_cast<int>(tc);
+  const int dtop = min(static_cast<int>(dhi), n - 1);
+  // (uniform in the wave, and in the workgroup when it shares the tile: no cell of the band in this tile)
+  if (j0 >= n || j0 - (i0 + 31) > dtop) return;
+  const int T = static_cast<int>(thr);
   const int r = static_cast<int>(lane & 31u), h = static_cast<int>(lane >> 5);
   const int i = i0 + r, j = j0 + r;
 
@@ -168,9 +179,9 @@ k_tree_mid_mx(TreeBatch b, uint32_t dlo, uint32_t dhi, uint32_t thr, int outside
         mx_load<true>(rb, pb, kb, blo, bhi);
       }
     };
-    int qq = qlo + static_cast<int>(wave);
+    int qq = qlo + (KS == 1 ? 0 : static_cast<int>(wave));
     if (qq <= qhi) fetch(qq);
-    for (; qq <= qhi; qq += kMxWaves) {
+    for (; qq <= qhi; qq += KS) {
       const int ea = mx_scale(ra, lane), eb = mx_scale(rb, lane);
       float fa[16], fb[16];
 #pragma unroll
@@ -178,7 +189,7 @@ k_tree_mid_mx(TreeBatch b, uint32_t dlo, uint32_t dhi, uint32_t thr, int outside
         fa[e] = ra[e];
         fb[e] = rb[e];
       }
-      if (qq + kMxWaves <= qhi) fetch(qq + kMxWaves);
+      if (qq + KS <= qhi) fetch(qq + KS);
       f32x16 c;
 #pragma unroll
       for (int x = 0; x < 16; x++) c[x] = 0.f;
@@ -205,6 +216,26 @@ k_tree_mid_mx(TreeBatch b, uint32_t dlo, uint32_t dhi, uint32_t thr, int outside
       __builtin_amdgcn_wave_barrier();
     }
   }
+  auto finish = [&](int x, int mn, float s) {  // register x of the tile: row 8 (x / 4) + 4 h + x % 4, column r
+    const int ci = i0 + 8 * (x >> 2) + 4 * h + (x & 3), cj = j0 + r;
+    const int d = cj - ci;
+    if (ci < n && cj < n && d >= static_cast<int>(dlo) && d <= dtop) {
+      float2 o = make_float2(kEmpty, 0.f);
+      if (s > 0.f) {
+        // s 2^mn = (2 f) 2^(mn + e - 1), f in [0.5, 1); the exponent goes to nats in two exact pieces
+        const int I = mn + __builtin_amdgcn_frexp_expf(s) - 1;
+        const float fi = static_cast<float>(I);
+        o.x = fi * kLn2hi;
+        o.y = 2.f * __builtin_amdgcn_frexp_mantf(s) * ex2(fi * (kLn2lo * kL2E));
+      }
+      q.mid[(static_cast<size_t>(prod) * b.ring + static_cast<uint32_t>(d) % b.ring) * q.vec + static_cast<uint32_t>(ci)] = o;
+    }
+  };
+  if (KS == 1) {
+#pragma unroll
+    for (int x = 0; x < 16; x++) finish(x, em[x], sm[x]);
+    return;
+  }
   // the four waves' partial sums meet: wave w finishes registers 4 w .. 4 w + 3 (rows 8 w + 4 h + t)
 #pragma unroll
   for (int x = 0; x < 16; x++) red[wave][x][lane] = make_float2(__int_as_float(em[x]), sm[x]);
@@ -222,19 +253,7 @@ k_tree_mid_mx(TreeBatch b, uint32_t dlo, uint32_t dhi, uint32_t thr, int outside
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < kMxWaves; w++) s += __builtin_ldexpf(v[w].y, __float_as_int(v[w].x) - mn);
-    const int ci = i0 + 8 * static_cast<int>(wave) + 4 * h + t, cj = j0 + r;
-    const int d = cj - ci;
-    if (ci < n && cj < n && d >= static_cast<int>(dlo) && d <= dtop) {
-      float2 o = make_float2(kEmpty, 0.f);
-      if (s > 0.f) {
-        // s 2^mn = (2 f) 2^(mn + e - 1), f in [0.5, 1); the exponent goes to nats in two exact pieces
-        const int I = mn + __builtin_amdgcn_frexp_expf(s) - 1;
-        const float fi = static_cast<float>(I);
-        o.x = fi * kLn2hi;
-        o.y = 2.f * __builtin_amdgcn_frexp_mantf(s) * ex2(fi * (kLn2lo * kL2E));
-      }
-      q.mid[(static_cast<size_t>(prod) * b.ring + static_cast<uint32_t>(d) % b.ring) * q.vec + static_cast<uint32_t>(ci)] = o;
-    }
+    finish(x, mn, s);
   }
 }
 
@@ -245,6 +264,11 @@ void launch_tree_mid_mx(const TreeBatch& b, bool outside, uint32_t dlo, uint32_t
   if (dlo >= max_n || dhi < dlo || nseq == 0) return;
   const uint32_t nbi = (max_n - dlo + 31u) / 32u;
   const uint32_t ntc = (31u + (dhi - dlo + 1u) + 31u) / 32u;
-  hipLaunchKernelGGL(k_tree_mid_mx, dim3(nbi * ntc * (outside ? 2u : 1u), nseq, 1), dim3(64 * kMxWaves), 0, st, b, dlo, dhi,
-                     thr, outside ? 1 : 0, nbi, ntc);
+  const uint32_t tiles = nbi * ntc * (outside ? 2u : 1u);
+  if (static_cast<uint64_t>(tiles) * nseq >= 4096u)
+    hipLaunchKernelGGL(k_tree_mid_mx<1>, dim3((tiles + kMxWaves - 1) / kMxWaves, nseq, 1), dim3(64 * kMxWaves),
+                       0, st, b, dlo, dhi, thr, outside ? 1 : 0, nbi, ntc);
+  else
+    hipLaunchKernelGGL(k_tree_mid_mx<kMxWaves>, dim3(tiles, nseq, 1), dim3(64 * kMxWaves), 0, st, b, dlo, dhi,
+                       thr, outside ? 1 : 0, nbi, ntc);
 }
