@@ -87,6 +87,8 @@ struct rnamc_ctx {
   // lane-per-cell sweeps with the mid-field in front of its band: the band's width (the in-band terms are
   // the lanes' own loops: narrower bands, fewer of them; the matrix-core mid-field takes the rest)
   int64_t tree_lane_band = 32;
+  // lane-per-cell sweeps: diagonals whose generic 2-loop sums share a launch (k_tlane_gen), 1 .. 3
+  int64_t tree_gen_batch = 3;
   // tree mode, banded sweeps: the far part of a launch's 2-loop blocks is summed by extra
   // workgroups of the previous launch (rnamc_tree.hip, Ahead)
   int64_t tree_ahead = 1;
@@ -986,6 +988,7 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
       const bool sync_out = (lane_mode & 2u) != 0u && c->tree_mid_sync != 0;
       const bool ahead = c->tree_ahead != 0 && (c->tree_tpc == 0 || c->tree_tpc == 64);
       bool use_far = false;  // (the first launch of a sweep forms its blocks whole)
+      uint32_t g_next = std::max(5u, dmin_in);  // lane-per-cell sweeps: the next diagonal without its generic 2-loop sums
       uint32_t d = dmin_in;
       uint32_t cur_band = ~0u;
       while (d < gmax) {
@@ -1020,6 +1023,14 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
         }
         const uint32_t thr = sync_in ? x * band : (x >= 3 ? (x - 1) * band : 0u);
         if (lane_mode & 1u) {
+          // (the generic 2-loop sums of diagonal d + 1, wanted by this launch's second role: three diagonals
+          // at once — their slots read X4 up to their own diagonal minus four, i.e. up to d - 1)
+          while (g_next <= d + 1 && g_next < gmax) {
+            const uint32_t gc = std::min<uint32_t>(static_cast<uint32_t>(c->tree_gen_batch), gmax - g_next);
+            launch_tlane_gen(b, contra, false, g_next, gc, gmax, active(g_next), st);
+            c->stats.launches_inside++;
+            g_next += gc;
+          }
           if (d == dmin_in) {  // (the first diagonal's closing-pair blocks)
             launch_tlane_inside(b, contra, ~0u, d, gmax, active(d), 0u, st);
             c->stats.launches_inside++;
@@ -1058,6 +1069,7 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
       // starts.  (The first enqueue also orders bulk_stream after the inside sweep's last reads of
       // the ring and after launch_tree_init.)
       int64_t dd = static_cast<int64_t>(gmax) - 1;
+      int64_t go_next = static_cast<int64_t>(gmax) - 5;  // (a generic enclosing 2-loop needs n >= d + 5)
       cur_band = ~0u;
       use_far = false;
       while (dd >= static_cast<int64_t>(dmin_out)) {
@@ -1089,6 +1101,15 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
         const uint32_t thr = sync_out ? ((x + 1) * band < gmax ? (x + 1) * band : 0u)
                                       : ((x + 2) * band < gmax ? (x + 2) * band : 0u);
         if (lane_mode & 2u) {
+          // (the generic enclosing 2-loops of diagonal du, wanted by this launch: three diagonals downwards at
+          // once — their slots read PX4 from their own diagonal plus four on, i.e. from du + 2)
+          while (go_next >= static_cast<int64_t>(du) && go_next >= static_cast<int64_t>(dmin_out)) {
+            const uint32_t gc = static_cast<uint32_t>(std::min<int64_t>(c->tree_gen_batch, go_next - static_cast<int64_t>(dmin_out) + 1));
+            launch_tlane_gen(b, contra, true, static_cast<uint32_t>(go_next), gc, gmax,
+                             active(static_cast<uint32_t>(go_next) - (gc - 1u)), st);
+            c->stats.launches_outside++;
+            go_next -= gc;
+          }
           if (du == gmax - 1) {  // (the top diagonal's enclosing 2-loops: none exist, the slots are written)
             launch_tlane_outside(b, contra, ~0u, du, gmax, active(du), 0u, st);
             c->stats.launches_outside++;
@@ -1384,6 +1405,8 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     c->tree_pol.mid_wgs = static_cast<uint32_t>(std::min<int64_t>(value, 1 << 20));
   } else if (k == "tree_ahead_waves" && value >= 0) {
     c->tree_pol.ahead_waves = static_cast<uint64_t>(value);
+  } else if (k == "tree_gen_batch" && value >= 1 && value <= 3) {
+    c->tree_gen_batch = value;
   } else if (k == "tree_lane_band" && value >= 32 && value <= 128 && value % 32 == 0) {
     c->tree_lane_band = value;
   } else if (k == "tree_mid_mx" && (value == 0 || value == 1)) {

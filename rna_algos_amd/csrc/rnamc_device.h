@@ -113,7 +113,10 @@ enum TreeMat : int {
   T_W_D = 34,    // outside: W
   T_LIST = 35,   // u32 per entry: row d holds the rows i of the cells (i, i + d) that may pair, in order; the
                  // count in the row's last entry (k_tlane_list; the 2-loop sums run a lane per LISTED cell)
-  T_COUNT = 36,
+  T_GEN_D = 36,  // float2 per cell over two slots: {max, sum} of a listed cell's generic 2-loop terms (k_tlane_gen,
+                 // three diagonals a launch; as ONE f32 logarithm it cost an ulp of a ~300-nat value per cell and
+                 // diagonal: 2.6e-4 in the probabilities at n = 257, measured)
+  T_COUNT = 38,
   // ... and in those sweeps these slots hold diagonal-major data as well:
   T_ZRE_D = T_QB,  // sums_rightmost_basepairs_external (the row-major sums_close has no reader there)
   T_QA_D = T_W_D,  // sums_accessible until the band is spread into T_QA (inside sweep)
@@ -217,6 +220,9 @@ void launch_tlane_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t d
                          uint32_t thr, hipStream_t st);
 void launch_tlane_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t d_b, uint32_t max_n, uint32_t nseq,
                           uint32_t thr, hipStream_t st);
+// generic 2-loop sums of the listed cells of `count` (<= 3) diagonals from g0 on (inside upwards, outside downwards)
+void launch_tlane_gen(const TreeBatch& b, bool contra, bool outside, uint32_t g0, uint32_t count, uint32_t max_n,
+                      uint32_t nseq, hipStream_t st);
 // the rows of the cells that may pair, diagonal by diagonal (after launch_tree_static)
 void launch_tlane_list(const TreeBatch& b, uint32_t max_n, uint32_t nseq, hipStream_t st);
 // the finished band [dlo, dhi] into the row- / column-major copies k_tree_mid and k_tree_ext read

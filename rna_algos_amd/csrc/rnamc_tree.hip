@@ -384,9 +384,9 @@ __global__ void __launch_bounds__(256) k_tree_init(TreeBatch b, int contra, int 
     const size_t total = static_cast<size_t>(T_COUNT) * sd.msz;
     if (b.lane) {
       // (lane-per-cell sweeps: k_tree_static writes MBC — the "may pair" flag — for every cell and the
-      // other statics where it is finite, their only readers; the lists are written whole: 20 of the 36 slots need no filler)
+      // other statics where it is finite, their only readers; the lists and the generic 2-loop sums are written whole: 22 of the 38 slots need no filler)
       for (int mi = 0; mi < T_COUNT; mi++) {
-        if (mi == T_HP || mi == T_MBC || (mi >= T_ACCS && mi < T_QB_D) || mi == T_LIST) continue;
+        if (mi == T_HP || mi == T_MBC || (mi >= T_ACCS && mi < T_QB_D) || mi >= T_LIST) continue;  // (.. T_LIST, T_GEN_D's two slots)
         float* p = base + static_cast<size_t>(mi) * sd.msz;
         for (size_t x = t0; x < sd.msz; x += stride) p[x] = kNegInf;
       }

@@ -107,6 +107,38 @@ __device__ __forceinline__ void lane_generic_step(Acc& acc, __amdgpu_buffer_rsrc
   for (int u = 0; u < 8; u++) x[u] = ((!TAIL || e + static_cast<uint32_t>(u) < cnt) && okl[u]) ? g[u] + ln8[u] : kNegInf;
   acc_add8(acc, x);
 }
+// two full steps of the wave at once: sixteen loads in flight before the first is used (a launch of the
+// batch form holds ~2 300 of these waves on a chip with room for 8 000: its time is the waves' chain of
+// round trips, ~15 of them with eight slots a step)
+template <bool OUTSIDE>
+__device__ __forceinline__ void lane_generic_step2(Acc& acc, __amdgpu_buffer_rsrc_t plane, const uint32_t* __restrict__ gs,
+                                                   const float* __restrict__ gl, uint32_t e0, uint32_t e1, uint32_t ld,
+                                                   uint32_t dbase, uint32_t i, uint32_t voff, uint32_t room) {
+  const u32x8 sa = *reinterpret_cast<const __attribute__((address_space(4))) u32x8*>(reinterpret_cast<uintptr_t>(gs + e0));
+  const u32x8 sb = *reinterpret_cast<const __attribute__((address_space(4))) u32x8*>(reinterpret_cast<uintptr_t>(gs + e1));
+  const f32x8 la = *reinterpret_cast<const __attribute__((address_space(4))) f32x8*>(reinterpret_cast<uintptr_t>(gl + e0));
+  const f32x8 lb = *reinterpret_cast<const __attribute__((address_space(4))) f32x8*>(reinterpret_cast<uintptr_t>(gl + e1));
+  float g[16];
+  bool okl[16];
+#pragma unroll
+  for (int u = 0; u < 16; u++) {
+    const uint32_t sl = u < 8 ? sa[u & 7] : sb[u & 7];
+    const uint32_t a = sl & 255u, sab = sl >> 8;
+    okl[u] = true;
+    if (OUTSIDE) okl[u] = a < i && sab - a < room;
+    const uint32_t soff = 4u * (OUTSIDE ? (dbase + sab) * ld - a : (dbase - sab) * ld + a);
+    g[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(plane, static_cast<int>(voff), static_cast<int>(soff), 0));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  float x[8], y[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    x[u] = okl[u] ? g[u] + la[u] : kNegInf;
+    y[u] = okl[u + 8] ? g[u + 8] + lb[u] : kNegInf;
+  }
+  acc_add8(acc, x);
+  acc_add8(acc, y);
+}
 template <bool CONTRA, bool OUTSIDE>
 __device__ __forceinline__ void lane_generic(Acc& acc, const TreeBatch& b, float* x4, size_t msz, uint32_t ld,
                                              uint32_t smax, uint32_t dbase, uint32_t i, const float4& st4, float own,
@@ -125,6 +157,8 @@ __device__ __forceinline__ void lane_generic(Acc& acc, const TreeBatch& b, float
     const uint32_t steps = (cnt + 7u) >> 3, full = cnt >> 3;
     Acc ac = acc_empty();
     uint32_t st = turn;
+    for (; st + kLaneParts < full; st += 2u * kLaneParts)
+      lane_generic_step2<OUTSIDE>(ac, plane, gs, gl, 8u * st, 8u * (st + kLaneParts), ld, dbase, i, voff, room);
     for (; st < full; st += kLaneParts) lane_generic_step<OUTSIDE, false>(ac, plane, gs, gl, 8u * st, cnt, ld, dbase, i, voff, room);
     if (st < steps) lane_generic_step<OUTSIDE, true>(ac, plane, gs, gl, 8u * st, cnt, ld, dbase, i, voff, room);
     turn = (turn + kLaneParts - steps % kLaneParts) % kLaneParts;
@@ -204,53 +238,51 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_inside(TreeBatch b, u
 #endif
   const size_t msz = static_cast<size_t>(q.m[1] - q.m[0]);
   if (blockIdx.x >= nb_a) {
-    // ---- closing-pair blocks of the listed cells of diagonal d_b
+    // ---- closing-pair blocks of the listed cells of diagonal d_b: hairpin, multibranch term, the explicit
+    // small 2-loops; the generic 2-loops' sum was formed by k_tlane_gen (T_GEN_D).  A lane per listed cell.
     const uint32_t db = d_b;
     if (db >= n) return;
     const uint32_t* __restrict__ list = lane_list(q, db);
     const uint32_t cnt = sload(list + (ld - 1u));
-    const uint32_t c0 = (blockIdx.x - nb_a) * 64u;
-    if (c0 >= cnt) return;  // (the whole block)
-    const bool valid = c0 + lane < cnt;
-    const uint32_t i = valid ? list[c0 + lane] : list[c0];
+    const uint32_t c = (blockIdx.x - nb_a) * (64u * kLaneParts) + threadIdx.x;
+    if (c >= cnt) return;
+    const uint32_t i = list[c];
     const size_t dg = static_cast<size_t>(db) * ld + i;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    Acc acc[1] = {acc_empty()};
+    Acc acc = acc_empty();
     const float mbc = q.m[T_MBC][dg];  // (finite: a listed cell)
-    if (part == 0u) {
-      const float hp = q.m[T_HP][dg];
-      const float4 n4 = reinterpret_cast<const float4*>(q.m[T_NEAR4])[dg];
-      const float4 n8 = CONTRA ? zero4 : reinterpret_cast<const float4*>(q.m[T_NEAR8])[dg];
-      const float qm = db >= 2u ? q.m[T_QM][dg - 2u * static_cast<size_t>(ld) + 1u] : kNegInf;  // Qm(i+1, j-1)
-      const float nr[8] = {n4.x, n4.y, n4.z, n4.w, n8.x, n8.y, n8.z, 0.f};
-      float xs[8];
-#pragma unroll
-      for (uint32_t t = 0; t < 8u; t++) {
-        xs[t] = kNegInf;
-        if (t < Special<CONTRA>::N) {
-          uint32_t a, bb;
-          Special<CONTRA>::slot(t, a, bb);
-          if (a + bb + 3u <= db) xs[t] = q.m[T_QB_D][static_cast<size_t>(db - 2u - a - bb) * ld + (i + 1u + a)] + nr[t];
-        }
-      }
-      acc_add4(acc[0], hp, qm + mbc, xs[0], xs[1]);
-      if (CONTRA) {
-        acc_add2(acc[0], xs[2], xs[3]);
-      } else {
-        acc_add4(acc[0], xs[2], xs[3], xs[4], xs[5]);
-        acc_add(acc[0], xs[6]);
-      }
-    }
+    const float hp = q.m[T_HP][dg];
+    const float4 n4 = reinterpret_cast<const float4*>(q.m[T_NEAR4])[dg];
+    const float4 n8 = CONTRA ? zero4 : reinterpret_cast<const float4*>(q.m[T_NEAR8])[dg];
+    const float qm = db >= 2u ? q.m[T_QM][dg - 2u * static_cast<size_t>(ld) + 1u] : kNegInf;  // Qm(i+1, j-1)
+    Acc gen = acc_empty();
 #ifdef RNAMC_DEBUG_KNOBS
     if (!(b.debug & 1))
 #endif
     if (db >= 5u) {  // (a generic slot has a + b >= 2)
-      const float4 cs = reinterpret_cast<const float4*>(q.m[T_CS4])[dg];
-      lane_generic<CONTRA, false>(acc[0], b, q.m[T_X4], msz, ld, min(db - 3u, 30u), db - 2u, i, cs, 0.f, 0u, part);
+      const float2 g2 = reinterpret_cast<const float2*>(q.m[T_GEN_D])[dg];
+      gen = Acc{g2.x, g2.y};
     }
-    if (!lane_join<1>(acc, red, lane, part)) return;
-    if (!valid) return;
-    const float qb = acc_value(acc[0]);
+    const float nr[8] = {n4.x, n4.y, n4.z, n4.w, n8.x, n8.y, n8.z, 0.f};
+    float xs[8];
+#pragma unroll
+    for (uint32_t t = 0; t < 8u; t++) {
+      xs[t] = kNegInf;
+      if (t < Special<CONTRA>::N) {
+        uint32_t a, bb;
+        Special<CONTRA>::slot(t, a, bb);
+        if (a + bb + 3u <= db) xs[t] = q.m[T_QB_D][static_cast<size_t>(db - 2u - a - bb) * ld + (i + 1u + a)] + nr[t];
+      }
+    }
+    acc_add4(acc, hp, qm + mbc, xs[0], xs[1]);
+    if (CONTRA) {
+      acc_add2(acc, xs[2], xs[3]);
+    } else {
+      acc_add4(acc, xs[2], xs[3], xs[4], xs[5]);
+      acc_add(acc, xs[6]);
+    }
+    acc_merge(acc, gen);
+    const float qb = acc_value(acc);
     if (qb > kNegInf) {
       const float4 in4 = reinterpret_cast<const float4*>(q.m[T_IN4])[dg];
       q.m[T_QB_D][dg] = qb;
@@ -336,50 +368,41 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_outside(TreeBatch b, 
 #endif
   const size_t msz = static_cast<size_t>(q.m[1] - q.m[0]);
   if (blockIdx.x >= nb_a) {
+    // (the explicit small 2-loops around the listed cells of diagonal d_b: they read diagonals d_b + 2 ..
+    // d_b + 6, the most recent ones; the generic ones were summed by k_tlane_gen, T_GEN_D)
     const uint32_t db = d_b;
     if (db >= n) return;
     const uint32_t* __restrict__ list = lane_list(q, db);
     const uint32_t cnt = sload(list + (ld - 1u));
-    const uint32_t c0 = (blockIdx.x - nb_a) * 64u;
-    if (c0 >= cnt) return;
-    const bool valid = c0 + lane < cnt;
-    const uint32_t i = valid ? list[c0 + lane] : list[c0];
+    const uint32_t c = (blockIdx.x - nb_a) * (64u * kLaneParts) + threadIdx.x;
+    if (c >= cnt) return;
+    const uint32_t i = list[c];
     const uint32_t j = i + db;
     const size_t dg = static_cast<size_t>(db) * ld + i;
     const uint32_t room = n - 1u - j;  // bases right of j
-    const float qb = valid ? q.m[T_QB_D][dg] : kNegInf;
-    Acc acc[1] = {acc_empty()};
+    const float qb = q.m[T_QB_D][dg];
+    Acc acc = acc_empty();
     if (qb > kNegInf) {
-      if (part == 0u) {
-        float xs[8];
+      float xs[8];
 #pragma unroll
-        for (uint32_t t = 0; t < 8u; t++) {
-          xs[t] = kNegInf;
-          if (t < Special<CONTRA>::N) {
-            uint32_t a, bb;
-            Special<CONTRA>::slot(t, a, bb);
-            if (a < i && bb < room) {
-              const uint32_t k = i - 1u - a, dd = db + 2u + a + bb;
-              const float nqb = q.m[T_QB_D][static_cast<size_t>(dd) * ld + k];
-              const float npk = q.out[tri_off(n, dd) + k];
-              const float nsc = (t < 4u ? q.m[T_NEAR4] : q.m[T_NEAR8])[4u * (static_cast<size_t>(dd) * ld + k) + (t & 3u)];
-              if (nqb > kNegInf) xs[t] = ((npk + qb) - nqb) + nsc;
-            }
+      for (uint32_t t = 0; t < 8u; t++) {
+        xs[t] = kNegInf;
+        if (t < Special<CONTRA>::N) {
+          uint32_t a, bb;
+          Special<CONTRA>::slot(t, a, bb);
+          if (a < i && bb < room) {
+            const uint32_t k = i - 1u - a, dd = db + 2u + a + bb;
+            const float nqb = q.m[T_QB_D][static_cast<size_t>(dd) * ld + k];
+            const float npk = q.out[tri_off(n, dd) + k];
+            const float nsc = (t < 4u ? q.m[T_NEAR4] : q.m[T_NEAR8])[4u * (static_cast<size_t>(dd) * ld + k) + (t & 3u)];
+            if (nqb > kNegInf) xs[t] = ((npk + qb) - nqb) + nsc;
           }
         }
-        acc_add4(acc[0], xs[0], xs[1], xs[2], xs[3]);
-        if (!CONTRA) acc_add4(acc[0], xs[4], xs[5], xs[6], kNegInf);
       }
-#ifdef RNAMC_DEBUG_KNOBS
-      if (!(b.debug & 1))
-#endif
-      if (n >= db + 5u) {  // (a generic slot has a + b >= 2, and a + b <= (i - 1) + room = n - 3 - d)
-        const float4 in4 = reinterpret_cast<const float4*>(q.m[T_IN4])[dg];
-        lane_generic<CONTRA, true>(acc[0], b, q.m[T_X4], msz, ld, min(n - 3u - db, 30u), db + 2u, i, in4, qb, room, part);
-      }
+      acc_add4(acc, xs[0], xs[1], xs[2], xs[3]);
+      if (!CONTRA) acc_add4(acc, xs[4], xs[5], xs[6], kNegInf);
     }
-    if (!lane_join<1>(acc, red, lane, part)) return;
-    if (valid) reinterpret_cast<float2*>(q.m[T_P2_D])[dg] = make_float2(acc[0].m, acc[0].s);
+    reinterpret_cast<float2*>(q.m[T_P2_D])[dg] = make_float2(acc.m, acc.s);
     return;
   }
   const uint32_t i = blockIdx.x * 64u + lane;
@@ -443,6 +466,13 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_outside(TreeBatch b, 
   const float zpi = q.zp[i], zsj = q.zs[j + 1u], ztot = sload(q.zp + n);
   const float2 p2 = reinterpret_cast<const float2*>(q.m[T_P2_D])[dg];
   Acc pa = Acc{p2.x, p2.y};
+#ifdef RNAMC_DEBUG_KNOBS
+  if (!(b.debug & 1))
+#endif
+  if (n >= d + 5u) {  // (the generic enclosing 2-loops: k_tlane_gen)
+    const float2 g2 = reinterpret_cast<const float2*>(q.m[T_GEN_D])[dg];
+    acc_merge(pa, Acc{g2.x, g2.y});
+  }
   acc_add(pa, CONTRA ? (((zpi + zsj) + qa) + ext_bp) - ztot : ((zpi + qa) + zsj) - ztot);
   const float A = qa + abr;
   acc_add(pa, A + acc_value(acc[1]));
@@ -460,6 +490,73 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_outside(TreeBatch b, 
     x4[2u * msz + dg] = pq + cs.z;
     x4[3u * msz + dg] = pq + cs.w;
   }
+}
+
+// ---- the generic 2-loops (a + b >= 2: ~490 slots a cell, the bulk of the sweeps' loads) of the listed cells
+// of kGenDiags CONSECUTIVE diagonals in one launch.  A cell's slots read the 29 diagonals from four below
+// (inside) / above (outside) its own, and so do its neighbours' on the next diagonal, one row of slots
+// further: a launch per diagonal fetched every line once per diagonal — 12 % L2 hits, the group's window
+// is ~70 MB a launch — i.e. each ~29 times over the sweep.  Here the workgroup's twelve waves are three
+// diagonals x four parts over the same stretch of the lists (the same rows, give or take the lists'
+// drift), in step through the slots ordered by a + b: the lines meet in the CU's L1.  Possible because
+// the generic slots never touch the last three diagonals.  (Four diagonals — up to the newest diagonal
+// the slots may read — gave results that differed under Turner tables, deterministically, and agreed
+// again when the sums were formed a second time just in time; three agree to the bit with one diagonal a
+// launch on every length tried, scripts/gen_batch_check.py: the batch stays at three, the cause is not understood.)
+// The sum of a cell goes to T_GEN_D as a {max, sum} pair; the just-in-time rest of the block — hairpin,
+// multibranch, explicit small loops — stays with the sweep's launches.
+constexpr uint32_t kGenDiags = 3u;
+template <bool CONTRA, bool OUTSIDE>
+__global__ void __launch_bounds__(64 * kLaneParts * kGenDiags) k_tlane_gen(TreeBatch b, uint32_t g0, uint32_t gcount) {
+  __shared__ float2 red[kGenDiags][kLaneParts][64];
+  const TSeq q = load_tseq(b, blockIdx.y);
+  const uint32_t n = q.n, ld = q.ld;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)));
+  const uint32_t part = wave % kLaneParts, ds = wave / kLaneParts;
+#ifdef RNAMC_DEBUG_KNOBS
+  if (b.debug & 5) return;
+#endif
+  const uint32_t c0 = blockIdx.x * 64u;
+  const size_t msz = static_cast<size_t>(q.m[1] - q.m[0]);
+  // this wave's diagonal (inside: g0 + ds, outside: g0 - ds) and whether it has generic slots at all
+  const uint32_t e = OUTSIDE ? g0 - ds : g0 + ds;
+  bool live = ds < gcount && (OUTSIDE ? (ds <= g0 && n >= e + 5u) : (e < n && e >= 5u));
+  uint32_t cnt = 0;
+  const uint32_t* __restrict__ list = nullptr;
+  if (live) {
+    list = lane_list(q, e);
+    cnt = sload(list + (ld - 1u));
+    live = c0 < cnt;
+  }
+  Acc acc = acc_empty();
+  uint32_t i = 0;
+  bool valid = false;
+  size_t dg = 0;
+  if (live) {
+    valid = c0 + lane < cnt;
+    i = valid ? list[c0 + lane] : list[c0];
+    dg = static_cast<size_t>(e) * ld + i;
+    if (!OUTSIDE) {
+      const float4 cs = reinterpret_cast<const float4*>(q.m[T_CS4])[dg];
+      lane_generic<CONTRA, false>(acc, b, q.m[T_X4], msz, ld, min(e - 3u, 30u), e - 2u, i, cs, 0.f, 0u, part);
+    } else {
+      const float qb = valid ? q.m[T_QB_D][dg] : kNegInf;
+      if (qb > kNegInf) {
+        const float4 in4 = reinterpret_cast<const float4*>(q.m[T_IN4])[dg];
+        lane_generic<CONTRA, true>(acc, b, q.m[T_X4], msz, ld, min(n - 3u - e, 30u), e + 2u, i, in4, qb, n - 1u - (i + e), part);
+      }
+    }
+  }
+  if (part != 0u) red[ds][part][lane] = make_float2(acc.m, acc.s);
+  __syncthreads();
+  if (part != 0u || !live || !valid) return;
+#pragma unroll
+  for (uint32_t p2 = 1; p2 < kLaneParts; p2++) {
+    const float2 v = red[ds][p2][lane];
+    acc_merge(acc, Acc{v.x, v.y});
+  }
+  reinterpret_cast<float2*>(q.m[T_GEN_D])[dg] = make_float2(acc.m, acc.s);
 }
 
 // ---- a finished band of diagonals [dlo, dhi] from the diagonal-major matrices into the row- and
@@ -523,12 +620,29 @@ void launch_tlane_list(const TreeBatch& b, uint32_t max_n, uint32_t nseq, hipStr
   hipLaunchKernelGGL(k_tlane_list, dim3(max_n, nseq, 1), dim3(256), 0, st, b);
 }
 
-// d: the diagonal of the per-row role (>= max_n: none); d_b: the diagonal whose listed cells take their 2-loop
-// sums in this launch (>= max_n: none)
+// the generic 2-loop sums of the listed cells of `count` (<= 3) diagonals from g0 on (inside: upwards,
+// outside: downwards): see k_tlane_gen for when a batch may run
+void launch_tlane_gen(const TreeBatch& b, bool contra, bool outside, uint32_t g0, uint32_t count, uint32_t max_n,
+                      uint32_t nseq, hipStream_t st) {
+  if (count == 0u || nseq == 0u) return;
+  const uint32_t dmin = outside ? g0 - (count - 1u) : g0;  // the longest diagonal of the batch
+  if (dmin >= max_n) return;
+  const dim3 grid((max_n - dmin + 63u) / 64u, nseq, 1), block(64 * kLaneParts * kGenDiags);
+  if (contra) {
+    if (outside) hipLaunchKernelGGL((k_tlane_gen<true, true>), grid, block, 0, st, b, g0, count);
+    else hipLaunchKernelGGL((k_tlane_gen<true, false>), grid, block, 0, st, b, g0, count);
+  } else {
+    if (outside) hipLaunchKernelGGL((k_tlane_gen<false, true>), grid, block, 0, st, b, g0, count);
+    else hipLaunchKernelGGL((k_tlane_gen<false, false>), grid, block, 0, st, b, g0, count);
+  }
+}
+
+// d: the diagonal of the per-row role (>= max_n: none); d_b: the diagonal whose listed cells take the
+// just-in-time part of their 2-loop sums in this launch (>= max_n: none)
 void launch_tlane_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t d_b, uint32_t max_n, uint32_t nseq,
                           uint32_t thr, hipStream_t st) {
   const uint32_t nb_a = d < max_n ? (max_n - d + 63u) / 64u : 0u;
-  const uint32_t nb_b = d_b < max_n ? (max_n - d_b + 63u) / 64u : 0u;
+  const uint32_t nb_b = d_b < max_n ? (max_n - d_b + 64u * kLaneParts - 1u) / (64u * kLaneParts) : 0u;
   if (nb_a + nb_b == 0u || nseq == 0u) return;
   if (contra)
     hipLaunchKernelGGL(k_tlane_outside<true>, dim3(nb_a + nb_b, nseq, 1), dim3(64 * kLaneParts), 0, st, b, d, thr, nb_a, d_b);
@@ -539,7 +653,7 @@ void launch_tlane_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t 
 void launch_tlane_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t d_b, uint32_t max_n, uint32_t nseq,
                          uint32_t thr, hipStream_t st) {
   const uint32_t nb_a = d < max_n ? (max_n - d + 63u) / 64u : 0u;
-  const uint32_t nb_b = d_b < max_n ? (max_n - d_b + 63u) / 64u : 0u;
+  const uint32_t nb_b = d_b < max_n ? (max_n - d_b + 64u * kLaneParts - 1u) / (64u * kLaneParts) : 0u;
   if (nb_a + nb_b == 0u || nseq == 0u) return;
   if (contra)
     hipLaunchKernelGGL(k_tlane_inside<true>, dim3(nb_a + nb_b, nseq, 1), dim3(64 * kLaneParts), 0, st, b, d, thr, nb_a, d_b);

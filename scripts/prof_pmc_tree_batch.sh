@@ -21,7 +21,7 @@ python3 - <<PY
 import csv, glob, os, collections
 out = "$OUT"
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
-names = ("k_tlane_inside", "k_tlane_outside", "k_tree_mid_mx", "k_tree_mid", "k_tree_static", "k_tree_init", "k_tlane_list",
+names = ("k_tlane_gen", "k_tlane_inside", "k_tlane_outside", "k_tree_mid_mx", "k_tree_mid", "k_tree_static", "k_tree_init", "k_tlane_list",
          "k_tlane_spread", "k_tree_ext", "k_tree_finalize")
 for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
