@@ -164,6 +164,48 @@ def tree_bytes(n, f, contra, band=64):
     return {"b_8d": b_8d, "inside": inside, "outside": outside, "valu_slots": valu}
 
 
+def tree_batch_traffic():
+    """PMC record of the tree-order BATCH form (scripts/prof_traffic_tree_batch.sh: FETCH_SIZE x 2 +
+    WRITE_SIZE over one pass of a 1 000-sequence slice of the bench batch, and the slice's pass time
+    outside the profiler) -> (bytes per pass, seconds per pass, nt, source) or None."""
+    path = os.path.join(ROOT, "profiles", "r04_tree_batch_traffic.json")
+    try:
+        j = json.load(open(path))
+        return float(j["total_bytes_x2"]), float(j["pass_ms"]) * 1e-3, int(j["nt"]), "profiles/r04_tree_batch_traffic.json"
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def tree_batch_roofline(lens, f, contra, pass_s, ms_in, ms_out):
+    """The tree-order batch form's line: its HBM utilisation from MEASURED bytes (the slice's PMC record,
+    scaled by nothing: bytes and time of the same slice), and the 8d figure of the reference's loops
+    as a throughput (never a utilisation: the mode does not move those bytes)."""
+    from rna_algos_amd import workloads as W
+    b_8d = float(W.algorithmic_bytes(lens, contra, f))
+    r = {"kernel": "tree-order batch form: k_tlane_inside / k_tlane_outside (a lane per cell, one diagonal per "
+                   "launch), k_tlane_gen (generic 2-loop sums of the listed cells, three diagonals per launch), "
+                   "k_tree_mid_mx (mid-field of the cubic products on the matrix cores)",
+         "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "ms_inside_per_step": ms_in, "ms_outside_per_step": ms_out,
+         "reference_equivalent_throughput": {
+             "what": "SURVEY 8d bytes of the REFERENCE's loops for this batch over this pass: the contract's "
+                     "figure, not a utilisation (the mode replaces three cubic loops by prefix recurrences "
+                     "and matrix-core products)",
+             "GB/s": b_8d / pass_s / 1e9, "of_peak": b_8d / pass_s / 1e9 / HBM_PEAK_GBS}}
+    t = tree_batch_traffic()
+    if t:
+        tb, ts, tnt, src = t
+        r.update({"achieved": tb / ts / 1e9, "frac": tb / ts / 1e9 / HBM_PEAK_GBS, "traffic": tb,
+                  "traffic_source": src,
+                  "bytes": f"PMC FETCH_SIZE x 2 + WRITE_SIZE of one pass over a 1 000-sequence slice of this batch "
+                           f"({tnt} nt, every 10th sequence) over that slice's pass time: MEASURED bytes, the "
+                           f"hardware utilisation of the mode on this workload"})
+    else:
+        r.update({"achieved": None, "frac": None, "traffic": None,
+                  "bytes": "no PMC record of the batch form committed (scripts/prof_traffic_tree_batch.sh)"})
+    return r
+
+
 def tree_leg(ctx, torch, dev, stream, seq, contra, reps, f, ref=None):
     """ms per sequence of ONE sequence in tree-order mode (median of `reps` calls after one
     warm-up call, device-resident), its rooflines, and its deviation from the reference-order
@@ -398,6 +440,8 @@ def main():
                     help="no per-kernel HIP events in the last warm-up pass")
     ap.add_argument("--no-n4096", action="store_true",
                     help="skip the single n=4096 sequence (second half of BASELINE.json's metric)")
+    ap.add_argument("--no-tree-batch", action="store_true",
+                    help="skip the tree-order pass of the same batch (value_tree, a second figure)")
     ap.add_argument("--no-transfers", action="store_true",
                     help="skip the host-buffer pass (value_with_transfers)")
     ap.add_argument("--time-budget-s", type=float, default=555.0,
@@ -693,9 +737,11 @@ def main():
     # parity, outside the timed region: batch members with committed oracle checksums
     checked = failed = 0
     tree_dev = None
-    if tree and args.workload == "batch10k" and args.param_seed == 1:
-        # tree-order run: the golden members once more in REFERENCE order (checked against the oracle's
-        # sha256), and the tree-order result's distance from that
+    def tree_deviation():
+        """d_out / d_logz hold a TREE-order pass: the golden members once more in REFERENCE order (checked
+        against the oracle's sha256) and the tree-order result's distance from that
+        -> (checked, failed, record)"""
+        n_checked = n_failed = 0
         gold = {}
         for name in ("checksums_batch.json", "checksums_batch2k.json"):
             try:
@@ -708,32 +754,37 @@ def main():
             idx = int(key.split("_")[0][len("batch"):])
             if key.endswith("contra") == contra and idx in where and idx < args.batch_count:
                 picks.append((where[idx], info))
-        if picks:
-            ctx.set("summation_mode", 0)
-            try:
-                rmats, rz = ctx.bpp_batch([my_seqs[x] for x, _ in picks], contra, False)
-            finally:
-                ctx.set("summation_mode", 1)
-            worst_p = worst_z = 0.0
-            keys_equal = True
-            for (x, info), rm, z0 in zip(picks, rmats, rz):
-                checked += 1
-                ref = np.asarray(rm.packed)
-                if golden_digest(ref) != info["sha256"]:
-                    failed += 1
-                got = d_out[int(out_offsets[x]):int(out_offsets[x + 1])].cpu().numpy()
-                ka, kb = got >= -0.5, ref >= -0.5
-                keys_equal = keys_equal and bool(np.array_equal(ka, kb))
-                both = ka & kb
-                worst_p = max(worst_p, float(np.abs(got[both].astype(np.float64) - ref[both]).max()))
-                worst_z = max(worst_z, abs(float(d_logz[x]) - float(z0)))
-            tree_dev = {"members": len(picks), "key_sets_equal": keys_equal, "max_abs_dp": worst_p,
-                        "max_abs_d_lnZ": worst_z,
-                        "note": "against the reference-order result of the same sequences in the same run (itself "
-                                "sha256-identical to the oracle); the reference's fold is approximate: this is ITS "
-                                "distance from an order-free f32 sum (f64 fixtures: tests/test_gpu_tree.py)"}
-            if not keys_equal:
-                failed += 1
+        if not picks:
+            return 0, 0, None
+        ctx.set("summation_mode", 0)
+        try:
+            rmats, rz = ctx.bpp_batch([my_seqs[x] for x, _ in picks], contra, False)
+        finally:
+            ctx.set("summation_mode", 1)
+        worst_p = worst_z = 0.0
+        keys_equal = True
+        for (x, info), rm, z0 in zip(picks, rmats, rz):
+            n_checked += 1
+            ref = np.asarray(rm.packed)
+            if golden_digest(ref) != info["sha256"]:
+                n_failed += 1
+            got = d_out[int(out_offsets[x]):int(out_offsets[x + 1])].cpu().numpy()
+            ka, kb = got >= -0.5, ref >= -0.5
+            keys_equal = keys_equal and bool(np.array_equal(ka, kb))
+            both = ka & kb
+            worst_p = max(worst_p, float(np.abs(got[both].astype(np.float64) - ref[both]).max()))
+            worst_z = max(worst_z, abs(float(d_logz[x]) - float(z0)))
+        rec = {"members": len(picks), "key_sets_equal": keys_equal, "max_abs_dp": worst_p,
+               "max_abs_d_lnZ": worst_z,
+               "note": "against the reference-order result of the same sequences in the same run (itself "
+                       "sha256-identical to the oracle); the reference's fold is approximate: this is ITS "
+                       "distance from an order-free f32 sum (f64 fixtures: tests/test_gpu_tree.py)"}
+        if not keys_equal:
+            n_failed += 1
+        return n_checked, n_failed, rec
+
+    if tree and args.workload == "batch10k" and args.param_seed == 1:
+        checked, failed, tree_dev = tree_deviation()
     if not tree and args.workload == "batch10k" and args.param_seed == 1:
         try:
             gold = json.load(open(os.path.join(ROOT, "tests", "golden", "checksums_batch.json")))["cases"]
@@ -886,21 +937,8 @@ def main():
             res["deviation_from_reference_order"] = tree_dev
             for k in ("roofline_tail", "roofline_outside_sweep", "roofline_inside"):
                 res.pop(k, None)
-            named = float(sum(tree_bytes(int(n_), f, contra)["inside"] + tree_bytes(int(n_), f, contra)["outside"]
-                              for n_ in lens))
-            sweep_ms = (ms_in + ms_out) / max(steps, 1)
-            res["roofline"] = {
-                "kernel": "tree-order sweeps of the whole batch (k_tree_* launches, one wave per cell pair, with "
-                          "k_tree_mid / k_tree_ext beside them)",
-                "bound": "hbm", "achieved": named / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": named / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sweep_ms > 0 else 0.0, "traffic": None,
-                "bytes": "bytes the tree-order kernels' loads and stores name, summed over the batch (no PMC record "
-                         "for this workload)",
-                "note": "bound by wave slots over wave lifetime (one wave per cell pair: ~1.3 ns per cell), not by "
-                        "bytes: DESIGN.md section 8",
-                "ms_inside_per_step": ms_in / max(steps, 1), "ms_outside_per_step": ms_out / max(steps, 1),
-            }
+            res["roofline"] = tree_batch_roofline(lens.astype(np.float64), f, contra, elapsed / max(steps, 1),
+                                                  ms_in / max(steps, 1), ms_out / max(steps, 1))
         if args.workload != "batch10k":
             # ms per sequence: median over the timed steps (>= 5 after a warm-up)
             res["ms_per_seq"] = float(np.median(step_s)) * 1e3
@@ -956,6 +994,42 @@ def main():
             else:
                 notes.append("cpu_baseline leg skipped: time budget")
                 res["cpu_baseline"] = None
+        if (not tree and args.workload == "batch10k" and world == 1 and not args.rehearse_shard
+                and not args.no_tree_batch and args.param_seed == 1):
+            # the SAME batch in the tree-order summation mode, a second figure (never `value`): one warm-up
+            # pass, one timed pass, the golden members compared with their reference-order results.  Last
+            # leg, and only when the time budget has room for it.
+            est = pass_s / 2.5
+            if room_for(2.0 * est + 8.0):
+                ctx.set("summation_mode", 1)
+                try:
+                    tt = []
+                    for _ in range(2):
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        step()
+                        torch.cuda.synchronize()
+                        tt.append(time.perf_counter() - t0)
+                    stt = ctx.stats()
+                    progress(f"tree-order leg: {tt[0]:.2f} s (warm-up), {tt[1]:.2f} s")
+                    n_c, n_f, dev_rec = tree_deviation()
+                finally:
+                    ctx.set("summation_mode", 0)
+                res["value_tree"] = float(lens.sum()) / tt[1]
+                res["tree_batch"] = {
+                    "what": "the same batch, device-resident, in the tree-order summation mode (rnamc_ctx_set "
+                            "summation_mode 1): order-free logsumexp sums, hardware exp2 / log2 — NOT bit-comparable "
+                            "with the reference and NOT the parity gate; `value` above is the reference-order run",
+                    "value": float(lens.sum()) / tt[1], "unit": "nt/s", "s_per_pass": tt[1], "s_warmup_pass": tt[0],
+                    "passes": "one warm-up, one timed",
+                    "deviation_from_reference_order": dev_rec,
+                    "reference_order_members_sha256_ok": n_c - n_f if dev_rec else None,
+                    "roofline": tree_batch_roofline(lf, f, contra, tt[1], stt["ms_inside"], stt["ms_outside"]),
+                }
+                if n_f:
+                    notes.append(f"tree-order leg: {n_f} of {n_c} golden members failed their check")
+            else:
+                notes.append("tree-order batch leg skipped: time budget")
         if steps != args.steps:
             res["steps_requested"] = args.steps
         if warm_done != args.warmup:

@@ -42,7 +42,7 @@ def run(ctx, seqs, contra, short, mode, **knobs):
         ctx.set("summation_mode", 0)
         for k in knobs:
             ctx.set(k, {"tree_two": 1, "tree_tpc": 0, "tree_band": 64, "tree_ahead": 1, "tree_lane": 1,
-                        "tree_mid_sync": 1, "tree_mid_mx": 1}[k])
+                        "tree_mid_sync": 1, "tree_mid_mx": 1, "tree_gen_batch": 3, "tree_lane_band": 32}[k])
 
 
 def deviation(a, b):
@@ -386,6 +386,37 @@ def test_tree_lane_per_cell_batch(ctx, params, contra, short):
     m1, z1 = run(ctx, [seqs[1]], contra, short, 1, tree_lane=2)
     same, dp = deviation(m1[0].packed, first[1].packed)
     assert same and dp <= 2 * (2e-5 + 2e-7 * len(seqs[1]))
+
+
+@pytest.mark.parametrize("contra", [False, True])
+def test_tree_batch_form_many_sequences(ctx, params, contra):
+    """The batch form at the size where its other launch shapes apply: 160 ragged sequences (300 .. 700 nt) —
+    a tile per wave in the matrix-core mid-field (k_tree_mid_mx<1>: at least 4 096 tiles a launch), the
+    generic 2-loop sums three diagonals a launch (k_tlane_gen) against one diagonal a launch, 256 listed
+    cells to a workgroup in the just-in-time role — against the wave-per-cell launches of the same mode
+    (rounding) and, for the two shortest, against the f64 evaluation of the recurrences."""
+    rng = np.random.default_rng(2026)
+    lens = sorted((int(x) for x in rng.integers(300, 701, size=160)), reverse=True)
+    seqs = [O.splitmix_seq(n, 31 * n + k) for k, n in enumerate(lens)]
+    base, zbase = run(ctx, seqs, contra, False, 1, tree_lane=0)
+    m, z = run(ctx, seqs, contra, False, 1)
+    st = ctx.stats()
+    m1, z1 = run(ctx, seqs, contra, False, 1, tree_gen_batch=1)
+    worst = 0.0
+    for s, a, a1, b0, za, zb in zip(seqs, m, m1, base, z, zbase):
+        same, dp = deviation(a.packed, b0.packed)
+        assert same and dp <= 2 * (2e-5 + 2e-7 * len(s)), (len(s), dp)
+        assert abs(float(za) - float(zb)) <= 3e-6 * abs(float(zb)), (len(s), float(za), float(zb))
+        # the same sums a diagonal at a time: the same terms in the same order within a cell
+        assert np.array_equal(np.asarray(a.packed), np.asarray(a1.packed)), len(s)
+        worst = max(worst, dp / (2e-5 + 2e-7 * len(s)))
+    for k in (len(seqs) - 1, len(seqs) - 2):
+        xb, xz = O.exact_bpp(params.ptr, seqs[k], contra, False)
+        same, dt = deviation(m[k].packed, xb)
+        assert same and dt <= 1.5 * (2e-5 + 2e-7 * len(seqs[k])), (len(seqs[k]), dt)
+        assert abs(float(z[k]) - xz) <= 2e-5 + 3e-6 * abs(xz)
+    print(f"contra={contra}: 160 sequences, batch form against wave-per-cell launches: worst |dp| = {worst:.2f} x "
+          f"(2e-5 + 2e-7 n); launches inside / outside {st['launches_inside']} / {st['launches_outside']}")
 
 
 def test_tree_edge_cases(ctx, params):
