@@ -517,46 +517,58 @@ __global__ void __launch_bounds__(64 * kLaneParts * kGenDiags) k_tlane_gen(TreeB
 #ifdef RNAMC_DEBUG_KNOBS
   if (b.debug & 5) return;
 #endif
-  const uint32_t c0 = blockIdx.x * 64u;
   const size_t msz = static_cast<size_t>(q.m[1] - q.m[0]);
   // this wave's diagonal (inside: g0 + ds, outside: g0 - ds) and whether it has generic slots at all
   const uint32_t e = OUTSIDE ? g0 - ds : g0 + ds;
-  bool live = ds < gcount && (OUTSIDE ? (ds <= g0 && n >= e + 5u) : (e < n && e >= 5u));
+  const bool has = ds < gcount && (OUTSIDE ? (ds <= g0 && n >= e + 5u) : (e < n && e >= 5u));
   uint32_t cnt = 0;
   const uint32_t* __restrict__ list = nullptr;
-  if (live) {
+  if (has) {
     list = lane_list(q, e);
     cnt = sload(list + (ld - 1u));
-    live = c0 < cnt;
   }
-  Acc acc = acc_empty();
-  uint32_t i = 0;
-  bool valid = false;
-  size_t dg = 0;
-  if (live) {
-    valid = c0 + lane < cnt;
-    i = valid ? list[c0 + lane] : list[c0];
-    dg = static_cast<size_t>(e) * ld + i;
-    if (!OUTSIDE) {
-      const float4 cs = reinterpret_cast<const float4*>(q.m[T_CS4])[dg];
-      lane_generic<CONTRA, false>(acc, b, q.m[T_X4], msz, ld, min(e - 3u, 30u), e - 2u, i, cs, 0.f, 0u, part);
-    } else {
-      const float qb = valid ? q.m[T_QB_D][dg] : kNegInf;
-      if (qb > kNegInf) {
-        const float4 in4 = reinterpret_cast<const float4*>(q.m[T_IN4])[dg];
-        lane_generic<CONTRA, true>(acc, b, q.m[T_X4], msz, ld, min(n - 3u - e, 30u), e + 2u, i, in4, qb, n - 1u - (i + e), part);
+  // The grid holds HALF the workgroups a diagonal of listed cells only could need (6 of 16 base combinations
+  // pair: a quarter of them found work, the others cost their launch): a workgroup walks its stretches of
+  // 64 list entries until the longest of its diagonals' lists ends (uniform: the counts travel through LDS).
+  __shared__ uint32_t cmax[kGenDiags];
+  if (part == 0u && lane == 0u) cmax[ds] = cnt;
+  __syncthreads();
+  uint32_t most = 0;
+#pragma unroll
+  for (uint32_t x = 0; x < kGenDiags; x++) most = max(most, cmax[x]);
+  for (uint32_t c0 = blockIdx.x * 64u; c0 < most; c0 += gridDim.x * 64u) {
+    const bool live = has && c0 < cnt;
+    Acc acc = acc_empty();
+    uint32_t i = 0;
+    bool valid = false;
+    size_t dg = 0;
+    if (live) {
+      valid = c0 + lane < cnt;
+      i = valid ? list[c0 + lane] : list[c0];
+      dg = static_cast<size_t>(e) * ld + i;
+      if (!OUTSIDE) {
+        const float4 cs = reinterpret_cast<const float4*>(q.m[T_CS4])[dg];
+        lane_generic<CONTRA, false>(acc, b, q.m[T_X4], msz, ld, min(e - 3u, 30u), e - 2u, i, cs, 0.f, 0u, part);
+      } else {
+        const float qb = valid ? q.m[T_QB_D][dg] : kNegInf;
+        if (qb > kNegInf) {
+          const float4 in4 = reinterpret_cast<const float4*>(q.m[T_IN4])[dg];
+          lane_generic<CONTRA, true>(acc, b, q.m[T_X4], msz, ld, min(n - 3u - e, 30u), e + 2u, i, in4, qb, n - 1u - (i + e), part);
+        }
       }
     }
-  }
-  if (part != 0u) red[ds][part][lane] = make_float2(acc.m, acc.s);
-  __syncthreads();
-  if (part != 0u || !live || !valid) return;
+    if (part != 0u) red[ds][part][lane] = make_float2(acc.m, acc.s);
+    __syncthreads();
+    if (part == 0u && live && valid) {
 #pragma unroll
-  for (uint32_t p2 = 1; p2 < kLaneParts; p2++) {
-    const float2 v = red[ds][p2][lane];
-    acc_merge(acc, Acc{v.x, v.y});
+      for (uint32_t p2 = 1; p2 < kLaneParts; p2++) {
+        const float2 v = red[ds][p2][lane];
+        acc_merge(acc, Acc{v.x, v.y});
+      }
+      reinterpret_cast<float2*>(q.m[T_GEN_D])[dg] = make_float2(acc.m, acc.s);
+    }
+    __syncthreads();  // (the next stretch's partial sums overwrite the exchange area)
   }
-  reinterpret_cast<float2*>(q.m[T_GEN_D])[dg] = make_float2(acc.m, acc.s);
 }
 
 // ---- a finished band of diagonals [dlo, dhi] from the diagonal-major matrices into the row- and
@@ -627,7 +639,7 @@ void launch_tlane_gen(const TreeBatch& b, bool contra, bool outside, uint32_t g0
   if (count == 0u || nseq == 0u) return;
   const uint32_t dmin = outside ? g0 - (count - 1u) : g0;  // the longest diagonal of the batch
   if (dmin >= max_n) return;
-  const dim3 grid((max_n - dmin + 63u) / 64u, nseq, 1), block(64 * kLaneParts * kGenDiags);
+  const dim3 grid(((max_n - dmin + 63u) / 64u + 1u) / 2u, nseq, 1), block(64 * kLaneParts * kGenDiags);
   if (contra) {
     if (outside) hipLaunchKernelGGL((k_tlane_gen<true, true>), grid, block, 0, st, b, g0, count);
     else hipLaunchKernelGGL((k_tlane_gen<true, false>), grid, block, 0, st, b, g0, count);
