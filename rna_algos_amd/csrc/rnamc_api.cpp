@@ -725,6 +725,35 @@ void build_tree_tabs(const rnamc_params& P, TreeTabs& T) {
         cnt++;
       }
     }
+    // class 3 in runs of four consecutive a per level
+    uint32_t ng = 0;
+    for (uint32_t s = 0; s <= 31u; s++) {
+      if (s <= 30u) {
+        uint32_t amin = ~0u, amax = 0u;
+        for (uint32_t a = 0; a <= s; a++) {
+          const uint32_t b = s - a;
+          const bool special = m == 0 ? ((a + b <= 1u) || (a >= 1u && a <= 2u && b >= 1u && b <= 2u)) : (a <= 1u && b <= 1u);
+          const bool c3 = !special && a >= 2u && b >= 2u && !((a == 2u && b == 3u) || (a == 3u && b == 2u));
+          if (!c3) continue;
+          amin = std::min(amin, a);
+          amax = std::max(amax, a);
+        }
+        for (uint32_t a0 = amin; amin != ~0u && a0 <= amax; a0 += 4u) {
+          T.g4slot[m][ng] = a0 | (s << 8);
+          for (uint32_t u = 0; u < 4u; u++) {
+            const uint32_t a = a0 + u, b = s - a;  // (a <= amax <= s - 2: b >= 2)
+            const uint32_t p = a <= 15u ? a * 32u + b : (30u - a) * 32u + b + a + 1u;
+            T.g4len[m][ng][u] = a <= amax ? T.len[m][p] : -INFINITY;
+          }
+          ng++;
+        }
+      }
+      T.g4count[m][s] = ng;
+    }
+    for (uint32_t x = 0; x < 8u && ng < 128u; x++, ng++) {  // (never counted: a step's reads stay inside the list)
+      T.g4slot[m][ng] = T.g4slot[m][ng - 1];
+      for (uint32_t u = 0; u < 4u; u++) T.g4len[m][ng][u] = -INFINITY;
+    }
   }
 }
 

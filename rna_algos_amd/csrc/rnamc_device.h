@@ -138,6 +138,13 @@ struct TreeTabs {
   float glen[2][544];
   uint32_t gstart[2][4];
   uint32_t gcount[2][4][32];
+  // ... and class 3 (both unpaired stretches >= 2 bases: three quarters of the slots) once more in runs: on a
+  // level a + b = s its slots are CONSECUTIVE a, i.e. consecutive floats of one diagonal row, so four of them
+  // are one 16-byte load.  Group g: first a | s << 8, the four length terms (-inf beyond the level's run);
+  // g4count[s] of the groups have a + b <= s; the list is padded with eight empty groups.
+  uint32_t g4slot[2][128];
+  float g4len[2][128][4];
+  uint32_t g4count[2][32];
 };
 struct TreeSeq {
   uint32_t n, ld;

@@ -139,14 +139,68 @@ __device__ __forceinline__ void lane_generic_step2(Acc& acc, __amdgpu_buffer_rsr
   acc_add8(acc, x);
   acc_add8(acc, y);
 }
+// Class 3 in runs (TreeTabs::g4slot): one step = four groups = sixteen slots off FOUR 16-byte loads and
+// four scalar offsets (the slot-by-slot form: sixteen loads, sixteen offsets at ~11 scalar instructions
+// each — the scalar unit, not the vector ALU, was the busiest part of these kernels by the SQ counters).
+// Inside the run of a level lies at rows i+1+a0 .. of diagonal dbase - s; outside at rows i-1-a0 .. DOWN
+// of diagonal dbase + s, so the load starts three floats lower and the elements come reversed.
+typedef float f32x4b __attribute__((ext_vector_type(4)));
+template <bool OUTSIDE>
+__device__ __forceinline__ void lane_generic_run4(Acc& acc, __amdgpu_buffer_rsrc_t plane, const uint32_t* __restrict__ gs,
+                                                  const float (*__restrict__ gl)[4], uint32_t g, uint32_t ng, uint32_t ld,
+                                                  uint32_t dbase, uint32_t i, uint32_t voff, uint32_t room) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 sl = *reinterpret_cast<const __attribute__((address_space(4))) u32x4*>(reinterpret_cast<uintptr_t>(gs + g));
+  f32x4b v[4];
+  float ln[16];
+  bool okl[16];
+#pragma unroll
+  for (int x = 0; x < 4; x++) {
+    const uint32_t a0 = sl[x] & 255u, sab = sl[x] >> 8;
+    const uint32_t soff = 4u * (OUTSIDE ? (dbase + sab) * ld - a0 - 3u : (dbase - sab) * ld + a0);
+    v[x] = __builtin_bit_cast(f32x4b, __builtin_amdgcn_raw_buffer_load_b128(plane, static_cast<int>(voff), static_cast<int>(soff), 0));
+    const f32x4b l4 = *reinterpret_cast<const __attribute__((address_space(4))) f32x4b*>(reinterpret_cast<uintptr_t>(&gl[g + x][0]));
+    const bool in = g + static_cast<uint32_t>(x) < ng;  // (uniform: a group past the cell's span counts for nothing)
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      ln[4 * x + u] = in ? l4[u] : kNegInf;
+      okl[4 * x + u] = true;
+      if (OUTSIDE) okl[4 * x + u] = a0 + static_cast<uint32_t>(u) < i && sab - a0 - static_cast<uint32_t>(u) < room;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  float xa[8], xb[8];
+#pragma unroll
+  for (int x = 0; x < 4; x++)
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const float val = OUTSIDE ? v[x][3 - u] : v[x][u];
+      const float t = okl[4 * x + u] ? val + ln[4 * x + u] : kNegInf;
+      if (x < 2) xa[4 * x + u] = t; else xb[4 * (x - 2) + u] = t;
+    }
+  acc_add8(acc, xa);
+  acc_add8(acc, xb);
+}
 template <bool CONTRA, bool OUTSIDE>
 __device__ __forceinline__ void lane_generic(Acc& acc, const TreeBatch& b, float* x4, size_t msz, uint32_t ld,
                                              uint32_t smax, uint32_t dbase, uint32_t i, const float4& st4, float own,
                                              uint32_t room, uint32_t part) {
   const uint32_t voff = 4u * (OUTSIDE ? max(i, 1u) - 1u : i + 1u);
   uint32_t turn = part;  // (the classes' steps are dealt to the block's waves in one round-robin)
+  {
+    // class 3 first, in runs of four slots (its own round-robin: steps of four groups)
+    const uint32_t ng = sload(&b.tabs->g4count[CONTRA ? 1 : 0][smax]);
+    const __amdgpu_buffer_rsrc_t plane =
+        __builtin_amdgcn_make_buffer_rsrc(x4 + 3u * msz, 0, static_cast<int>(msz * sizeof(float)), 0x00020000);
+    Acc ac = acc_empty();
+    for (uint32_t g = 4u * part; g < ng; g += 4u * kLaneParts)
+      lane_generic_run4<OUTSIDE>(ac, plane, b.tabs->g4slot[CONTRA ? 1 : 0], b.tabs->g4len[CONTRA ? 1 : 0], g, ng, ld, dbase, i,
+                                 voff, room);
+    ac.m += OUTSIDE ? own + st4.w : st4.w;  // (an empty accumulator stays empty: s = 0)
+    acc_merge(acc, ac);
+  }
 #pragma unroll
-  for (uint32_t c = 0; c < 4u; c++) {
+  for (uint32_t c = 0; c < 3u; c++) {
     const uint32_t start = sload(&b.tabs->gstart[CONTRA ? 1 : 0][c]);
     const uint32_t cnt = sload(&b.tabs->gcount[CONTRA ? 1 : 0][c][smax]);
     const uint32_t* __restrict__ gs = b.tabs->gslot[CONTRA ? 1 : 0] + start;
