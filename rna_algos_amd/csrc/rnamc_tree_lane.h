@@ -51,10 +51,10 @@ __device__ __forceinline__ void acc_add8(Acc& a, const float (&x)[8]) {
 }
 
 // (+) of A[oa(x)] + B[ob(x)] over this wave's steps of x in [lo, hi), x < mine (the lane's own end)
-template <typename FA, typename FB>
+template <uint32_t PARTS = kLaneParts, typename FA, typename FB>
 __device__ __forceinline__ void lane_sum(Acc& acc, const float* __restrict__ A, const float* __restrict__ B, uint32_t lo,
                                          uint32_t hi, uint32_t mine, uint32_t part, FA oa, FB ob) {
-  for (uint32_t x = lo + 8u * part; x < hi; x += 8u * kLaneParts) {
+  for (uint32_t x = lo + 8u * part; x < hi; x += 8u * PARTS) {
     float va[8], vb[8], v[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
@@ -221,25 +221,6 @@ __device__ __forceinline__ void lane_generic(Acc& acc, const TreeBatch& b, float
   }
 }
 
-// the block's partial sums of NA accumulators meet in its first wave (false: this wave is done)
-template <int NA>
-__device__ __forceinline__ bool lane_join(Acc (&a)[NA], float2 (*lds)[kLaneParts][64], uint32_t lane, uint32_t part) {
-  if (kLaneParts == 1u) return true;
-  if (part != 0u) {
-#pragma unroll
-    for (int x = 0; x < NA; x++) lds[x][part][lane] = make_float2(a[x].m, a[x].s);
-  }
-  __syncthreads();
-  if (part != 0u) return false;
-#pragma unroll
-  for (int x = 0; x < NA; x++)
-    for (uint32_t p2 = 1; p2 < kLaneParts; p2++) {
-      const float2 v = lds[x][p2][lane];
-      acc_merge(a[x], Acc{v.x, v.y});
-    }
-  return true;
-}
-
 // ---- the cells of a diagonal that may pair, in row order (k_tlane_list, once per group): the 2-loop sums
 // run over THESE — 6 of 16 base combinations are canonical, so a wave of 64 consecutive rows would walk
 // its ~490 slots with 24 lanes at work.  list[d * ld + c] = row of the c-th such cell of diagonal d, the
@@ -282,7 +263,6 @@ __global__ void __launch_bounds__(256) k_tlane_list(TreeBatch b) {
 template <bool CONTRA>
 __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_inside(TreeBatch b, uint32_t d, uint32_t thr, uint32_t nb_a,
                                                                  uint32_t d_b) {
-  __shared__ float2 red[1][kLaneParts][64];
   const TSeq q = load_tseq(b, blockIdx.y);
   const uint32_t n = q.n, ld = q.ld;
   const uint32_t lane = threadIdx.x & 63u;
@@ -349,9 +329,11 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_inside(TreeBatch b, u
     }
     return;
   }
-  // ---- the cells of diagonal d
-  const uint32_t i = blockIdx.x * 64u + lane;
-  if (blockIdx.x * 64u + d >= n) return;  // (the whole block: no barrier is left behind)
+  // ---- the cells of diagonal d: a wave per 64 rows, each lane its whole sums (with the mid-field in front of
+  // the band they are at most 2 x band terms: splitting them over four waves and joining through LDS cost more
+  // wave launches than it saved chain)
+  const uint32_t i = (blockIdx.x * kLaneParts + part) * 64u + lane;
+  if ((blockIdx.x * kLaneParts + part) * 64u + d >= n) return;  // (the whole wave; this role has no barrier)
   const bool valid = i + d < n;
   const size_t dg = static_cast<size_t>(d) * ld + i;
   Acc acc[1] = {acc_empty()};
@@ -367,13 +349,12 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_inside(TreeBatch b, u
     auto ob = [&](uint32_t x) { return static_cast<size_t>(d - 1u - x) * ld + x; };
     const uint32_t mine = valid ? n : 0u;
     if (thr != 0u) {
-      lane_sum(acc[0], A, B, 0u, d - thr, mine, part, oa, ob);
-      lane_sum(acc[0], A, B, thr, d - 1u, mine, part, oa, ob);
+      lane_sum<1>(acc[0], A, B, 0u, d - thr, mine, 0u, oa, ob);
+      lane_sum<1>(acc[0], A, B, thr, d - 1u, mine, 0u, oa, ob);
     } else {
-      lane_sum(acc[0], A, B, 0u, d - 1u, mine, part, oa, ob);
+      lane_sum<1>(acc[0], A, B, 0u, d - 1u, mine, 0u, oa, ob);
     }
   }
-  if (!lane_join<1>(acc, red, lane, part)) return;
   if (!valid) return;
   if (thr != 0u && d >= 2u) {
     const float2 mm = q.mid[static_cast<size_t>(d % b.ring) * q.vec + i];
@@ -412,7 +393,6 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_inside(TreeBatch b, u
 template <bool CONTRA>
 __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_outside(TreeBatch b, uint32_t d, uint32_t thr, uint32_t nb_a,
                                                                   uint32_t d_b) {
-  __shared__ float2 red[2][kLaneParts][64];
   const TSeq q = load_tseq(b, blockIdx.y);
   const uint32_t n = q.n, ld = q.ld;
   const uint32_t lane = threadIdx.x & 63u;
@@ -459,8 +439,8 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_outside(TreeBatch b, 
     reinterpret_cast<float2*>(q.m[T_P2_D])[dg] = make_float2(acc.m, acc.s);
     return;
   }
-  const uint32_t i = blockIdx.x * 64u + lane;
-  if (blockIdx.x * 64u + d >= n) return;
+  const uint32_t i = (blockIdx.x * kLaneParts + part) * 64u + lane;
+  if ((blockIdx.x * kLaneParts + part) * 64u + d >= n) return;  // (the whole wave; this role has no barrier)
   const bool valid = i + d < n;
   const uint32_t j = i + d;
   const size_t dg = static_cast<size_t>(d) * ld + i, dg1 = dg + ld;  // (i, j) and (i, j+1)
@@ -486,7 +466,7 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_outside(TreeBatch b, 
   if (hi > 1u) {
     auto oa = [&](uint32_t x) { return static_cast<size_t>(d + 1u + x) * ld; };
     auto ob = [&](uint32_t x) { return static_cast<size_t>(x - 1u) * ld + d + 1u; };
-    lane_sum(acc[0], w_d + i, q1_d + i, 1u, hi, room, part, oa, ob);
+    lane_sum<1>(acc[0], w_d + i, q1_d + i, 1u, hi, room, 0u, oa, ob);
   }
   // L_e cases one and three (594-601): x = 1 .., Q1(i-x, i-1) + R(i-1-x, j); banded: R's span d+1+x < thr
 #ifdef RNAMC_DEBUG_KNOBS
@@ -495,9 +475,8 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_outside(TreeBatch b, 
   if (hi > 1u) {
     auto oa = [&](uint32_t x) { return static_cast<size_t>(x - 1u) * ld - x; };
     auto ob = [&](uint32_t x) { return static_cast<size_t>(d + 1u + x) * ld - 1u - x; };
-    lane_sum(acc[1], q1_d + i, r_d + i, 1u, hi, paired ? i : 0u, part, oa, ob);
+    lane_sum<1>(acc[1], q1_d + i, r_d + i, 1u, hi, paired ? i : 0u, 0u, oa, ob);
   }
-  if (!lane_join<2>(acc, red, lane, part)) return;
   if (!valid) return;
   if (thr != 0u) {
     const float2 m1 = q.mid[(static_cast<size_t>(b.ring) + d % b.ring) * q.vec + i];
@@ -707,7 +686,7 @@ void launch_tlane_gen(const TreeBatch& b, bool contra, bool outside, uint32_t g0
 // just-in-time part of their 2-loop sums in this launch (>= max_n: none)
 void launch_tlane_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t d_b, uint32_t max_n, uint32_t nseq,
                           uint32_t thr, hipStream_t st) {
-  const uint32_t nb_a = d < max_n ? (max_n - d + 63u) / 64u : 0u;
+  const uint32_t nb_a = d < max_n ? (max_n - d + 64u * kLaneParts - 1u) / (64u * kLaneParts) : 0u;
   const uint32_t nb_b = d_b < max_n ? (max_n - d_b + 64u * kLaneParts - 1u) / (64u * kLaneParts) : 0u;
   if (nb_a + nb_b == 0u || nseq == 0u) return;
   if (contra)
@@ -718,7 +697,7 @@ void launch_tlane_outside(const TreeBatch& b, bool contra, uint32_t d, uint32_t 
 
 void launch_tlane_inside(const TreeBatch& b, bool contra, uint32_t d, uint32_t d_b, uint32_t max_n, uint32_t nseq,
                          uint32_t thr, hipStream_t st) {
-  const uint32_t nb_a = d < max_n ? (max_n - d + 63u) / 64u : 0u;
+  const uint32_t nb_a = d < max_n ? (max_n - d + 64u * kLaneParts - 1u) / (64u * kLaneParts) : 0u;
   const uint32_t nb_b = d_b < max_n ? (max_n - d_b + 64u * kLaneParts - 1u) / (64u * kLaneParts) : 0u;
   if (nb_a + nb_b == 0u || nseq == 0u) return;
   if (contra)

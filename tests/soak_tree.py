@@ -34,6 +34,13 @@ def main():
             "tree_ahead": int(rng.integers(0, 2)),
             "tree_two": int(rng.choice([0, 1, 1, 1])),
             "group_max_seqs": int(rng.choice([1, 3, 17, 8192])),
+            # the batch form (rnamc_tree_lane.h / rnamc_tree_mx.h): forced on in half of the rounds
+            # (by itself it takes calls of >= 65 536 nt), with its own knobs
+            "tree_lane": int(rng.choice([1, 2])),
+            "tree_lane_band": int(rng.choice([32, 32, 64])),
+            "tree_mid_sync": int(rng.choice([0, 1, 1])),
+            "tree_mid_mx": int(rng.choice([0, 1, 1])),
+            "tree_gen_batch": int(rng.choice([1, 2, 3, 3])),
         }
         ctx.set("summation_mode", 1)
         for k, v in knobs.items():
