@@ -750,6 +750,19 @@ void build_tree_tabs(const rnamc_params& P, TreeTabs& T) {
       }
       T.g4count[m][s] = ng;
     }
+    // classes 0 and 1 by level: (0, s), (s, 0), (1, s - 1), (s - 1, 1)
+    for (uint32_t s = 0; s < 32u; s++)
+      for (uint32_t u = 0; u < 4u; u++) {
+        T.elen[m][s][u] = -INFINITY;
+        if (s < 2u || s > 30u) continue;
+        const uint32_t a = u == 0u ? 0u : (u == 1u ? s : (u == 2u ? 1u : s - 1u)), b = s - a;
+        const bool special = m == 0 ? ((a + b <= 1u) || (a >= 1u && a <= 2u && b >= 1u && b <= 2u)) : (a <= 1u && b <= 1u);
+        const uint32_t cls = ((a == 0u) != (b == 0u)) ? 0u : (a == 1u || b == 1u) ? 1u : 3u;
+        if (special || cls != (u < 2u ? 0u : 1u)) continue;
+        if (u == 3u && s - 1u == 1u) continue;  // ((1, 1) once)
+        const uint32_t p = a <= 15u ? a * 32u + b : (30u - a) * 32u + b + a + 1u;
+        T.elen[m][s][u] = T.len[m][p];
+      }
     for (uint32_t x = 0; x < 8u && ng < 128u; x++, ng++) {  // (never counted: a step's reads stay inside the list)
       T.g4slot[m][ng] = T.g4slot[m][ng - 1];
       for (uint32_t u = 0; u < 4u; u++) T.g4len[m][ng][u] = -INFINITY;

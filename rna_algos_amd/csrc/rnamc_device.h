@@ -145,6 +145,10 @@ struct TreeTabs {
   uint32_t g4slot[2][128];
   float g4len[2][128][4];
   uint32_t g4count[2][32];
+  // ... and classes 0 and 1 (bulges, 1 x many) by LEVEL a + b = s: their slots are (0, s), (s, 0), (1, s - 1),
+  // (s - 1, 1) — the row's first and last two positions — so a level is four loads whose offsets are the level's
+  // row plus 0, s, 1, s - 1: no slot list at all.  elen[s] = the four length terms (-inf: not a generic slot).
+  float elen[2][32][4];
 };
 struct TreeSeq {
   uint32_t n, ld;

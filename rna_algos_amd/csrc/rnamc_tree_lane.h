@@ -181,6 +181,38 @@ __device__ __forceinline__ void lane_generic_run4(Acc& acc, __amdgpu_buffer_rsrc
   acc_add8(acc, xa);
   acc_add8(acc, xb);
 }
+// Classes 0 and 1 by level (TreeTabs::elen): step t = the levels 2 + 2 t and 3 + 2 t, four loads each at the
+// level's row plus 0, s (plane 0: bulges) and 1, s - 1 (plane 1: 1 x many); c0 / c1: the cell's own class scores.
+template <bool OUTSIDE>
+__device__ __forceinline__ void lane_generic_edge(Acc& acc, __amdgpu_buffer_rsrc_t p0, __amdgpu_buffer_rsrc_t p1,
+                                                  const float (*__restrict__ el)[4], uint32_t t, uint32_t smax, uint32_t ld,
+                                                  uint32_t dbase, uint32_t i, uint32_t voff, uint32_t room, float c0,
+                                                  float c1) {
+  float g[8], ln[8];
+  bool okl[8];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const uint32_t s = 2u + 2u * t + static_cast<uint32_t>(h);  // (uniform)
+    const bool in = s <= smax;
+    const uint32_t sc = in ? s : 2u;  // (a level past the cell's span: the first level's addresses, nothing counted)
+    const f32x4b l4 = *reinterpret_cast<const __attribute__((address_space(4))) f32x4b*>(reinterpret_cast<uintptr_t>(&el[sc][0]));
+    const uint32_t row4 = 4u * (OUTSIDE ? dbase + sc : dbase - sc) * ld;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t a = u == 0 ? 0u : (u == 1 ? sc : (u == 2 ? 1u : sc - 1u));
+      const uint32_t soff = OUTSIDE ? row4 - 4u * a : row4 + 4u * a;
+      g[4 * h + u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(u < 2 ? p0 : p1, static_cast<int>(voff), static_cast<int>(soff), 0));
+      ln[4 * h + u] = (in ? l4[u] : kNegInf) + (u < 2 ? c0 : c1);
+      okl[4 * h + u] = true;
+      if (OUTSIDE) okl[4 * h + u] = a < i && sc - a < room;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  float x[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) x[k] = okl[k] ? g[k] + ln[k] : kNegInf;
+  acc_add8(acc, x);
+}
 template <bool CONTRA, bool OUTSIDE>
 __device__ __forceinline__ void lane_generic(Acc& acc, const TreeBatch& b, float* x4, size_t msz, uint32_t ld,
                                              uint32_t smax, uint32_t dbase, uint32_t i, const float4& st4, float own,
@@ -199,8 +231,19 @@ __device__ __forceinline__ void lane_generic(Acc& acc, const TreeBatch& b, float
     ac.m += OUTSIDE ? own + st4.w : st4.w;  // (an empty accumulator stays empty: s = 0)
     acc_merge(acc, ac);
   }
+  {
+    // classes 0 and 1 by level
+    const __amdgpu_buffer_rsrc_t p0 = __builtin_amdgcn_make_buffer_rsrc(x4, 0, static_cast<int>(msz * sizeof(float)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t p1 =
+        __builtin_amdgcn_make_buffer_rsrc(x4 + msz, 0, static_cast<int>(msz * sizeof(float)), 0x00020000);
+    const float c0 = OUTSIDE ? own + st4.x : st4.x, c1 = OUTSIDE ? own + st4.y : st4.y;
+    Acc ac = acc_empty();
+    for (uint32_t t = part; t < smax / 2u; t += kLaneParts)  // (levels 2 .. smax, two a step)
+      lane_generic_edge<OUTSIDE>(ac, p0, p1, b.tabs->elen[CONTRA ? 1 : 0], t, smax, ld, dbase, i, voff, room, c0, c1);
+    acc_merge(acc, ac);
+  }
 #pragma unroll
-  for (uint32_t c = 0; c < 3u; c++) {
+  for (uint32_t c = 2u; c < 3u; c++) {
     const uint32_t start = sload(&b.tabs->gstart[CONTRA ? 1 : 0][c]);
     const uint32_t cnt = sload(&b.tabs->gcount[CONTRA ? 1 : 0][c][smax]);
     const uint32_t* __restrict__ gs = b.tabs->gslot[CONTRA ? 1 : 0] + start;
