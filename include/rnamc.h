@@ -252,7 +252,9 @@ int rnamc_ctx_set_params(rnamc_ctx* ctx, const rnamc_params* params);
  * nucleotides — the default —, 2 always), "tree_mid_sync" (lane-per-cell sweeps: a band's mid-field
  * kernel runs in front of the band on the sweep's own stream, default 1), "tree_lane_band" (the band
  * width of those sweeps: 32 / 64 / 96 / 128, default 32, never wider than "tree_band"), "tree_gen_batch"
- * (diagonals whose generic 2-loop sums share a launch there: 1 .. 3, default 3), "tree_mid_mx" (the
+ * (diagonals whose generic 2-loop sums share a launch there: 1 .. 3, default 3), "tree_dual" (every other
+ * group of such a call on a second stream with its own half of the workspace, so that two groups fill each
+ * other's launch gaps: default 1; device-resident entry only), "tree_mid_mx" (the
  * mid-field products on the matrix cores, k_tree_mid_mx: exponentials per operand element, one
  * v_mfma_f32_32x32x2_f32 multiply-add per term; default 1, 0 = the VALU form k_tree_mid).
  * Every knob is per context. */

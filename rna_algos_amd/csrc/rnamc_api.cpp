@@ -94,6 +94,13 @@ struct rnamc_ctx {
   int64_t tree_ahead = 1;
   TreePolicy tree_pol;  // launch shapes of the tree-order sweep ("tree_waves", "tree_short", ...)
   hipStream_t bulk_stream = nullptr;  // k_tree_mid, beside the sweep (lowest priority)
+  // tree mode, batch form: every other group of a call sweeps on a second stream with its own half of the
+  // workspace, side stream and event rings — two groups side by side fill each other's launch gaps (the
+  // per-diagonal launches cost ~8 us whatever they hold); "tree_dual" 0 switches it off
+  int64_t tree_dual = 1;
+  hipStream_t dual_stream = nullptr, bulk_stream2 = nullptr;
+  std::vector<hipEvent_t> ev_a2, ev_b2;
+  hipEvent_t ev_dual = nullptr;
   // does bulk_stream run beside the stream of the last banded call?  (probed once per stream:
   // tree_side_stream_probe; 0 unknown, 1 yes, 2 no -> unbanded sweeps on that stream)
   hipStream_t side_probed_for = nullptr;
@@ -871,6 +878,10 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
       (void)hipGetLastError();
     }
   }
+  // two groups side by side (see tree_dual): each gets half of the cap
+  bool dual = lane_mode != 0u && c->tree_mid_sync != 0 && c->tree_dual != 0 && hooks == nullptr &&
+              st != c->aux_stream && st != c->own_stream;
+  if (dual) ws_cap_floats /= 2;
   std::vector<TreeSeq>& tseqs = c->h_tseqs;
   tseqs.clear();
   tseqs.reserve(n_seqs);
@@ -923,8 +934,24 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
     c->group_out_floats.push_back(cur_out);
     c->group_begin.push_back(static_cast<uint32_t>(c->descs.size()));
   }
-  rc = ensure_ws(c, max_group_floats);
+  if (c->group_begin.size() < 3) dual = false;  // (a single group)
+  rc = ensure_ws(c, dual ? 2 * max_group_floats : max_group_floats);
   if (rc) return rc;
+  if (dual && !c->ev_dual) {
+    // (no new streams: a process's fifth and later streams share hardware queues on this runtime — the second
+    // group's sweep would sit in the first one's queue, measured: 698 instead of 556 ms — so the second group
+    // takes the two streams the context created first for the reference-order path, idle in this mode)
+    c->dual_stream = c->aux_stream;
+    c->bulk_stream2 = c->own_stream;
+    HIPCHK(hipEventCreateWithFlags(&c->ev_dual, hipEventDisableTiming));
+    for (size_t x = 0; x < c->ev_a.size(); x++) {
+      hipEvent_t ea, eb;
+      HIPCHK(hipEventCreateWithFlags(&ea, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+      c->ev_a2.push_back(ea);
+      c->ev_b2.push_back(eb);
+    }
+  }
   if (c->tseqs_cap < tseqs.size()) {
     if (c->d_tseqs) {
       HIPCHK(hipDeviceSynchronize());
@@ -949,7 +976,16 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
   }
   const uint32_t dmin_in = contra ? 0u : (RNAMC_MIN_SPAN_HAIRPIN_CLOSE - 1);
   const uint32_t dmin_out = (contra && allows_short) ? 1u : (RNAMC_MIN_SPAN_HAIRPIN_CLOSE - 1);
+  if (dual) {  // (the second stream starts behind whatever the caller's stream holds: the descriptors' copy)
+    HIPCHK(hipEventRecord(c->ev_dual, st));
+    HIPCHK(hipStreamWaitEvent(c->dual_stream, c->ev_dual, 0));
+  }
   for (size_t g = 0; g < n_groups; g++) {
+    const bool odd = dual && (g & 1u) != 0u;
+    hipStream_t gst = odd ? c->dual_stream : st;
+    hipStream_t gbulk = odd ? c->bulk_stream2 : c->bulk_stream;
+    std::vector<hipEvent_t>& gev_a = odd ? c->ev_a2 : c->ev_a;
+    std::vector<hipEvent_t>& gev_b = odd ? c->ev_b2 : c->ev_b;
     const uint32_t gb = c->group_begin[g], ge = c->group_begin[g + 1];
     const uint32_t nseq = ge - gb;
     const uint32_t gmax = c->descs[gb].n;
@@ -958,7 +994,7 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
     b.one = tseqs[gb];
     b.use_one = nseq == 1 ? 1u : 0u;
     b.bases = d_bases;
-    b.workspace = c->d_ws;
+    b.workspace = c->d_ws + (odd ? max_group_floats : 0);
     b.out = d_out;
     if (hooks) {
       rc = hooks->before(g, &b.out);
@@ -982,12 +1018,12 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
       }
       return lo;
     };
-    if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 0], st));
-    launch_tree_init(b, nseq, gmax, contra, 0, st);
-    launch_tree_static(b, contra, nseq, gmax, st);
+    if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 0], gst));
+    launch_tree_init(b, nseq, gmax, contra, 0, gst);
+    launch_tree_static(b, contra, nseq, gmax, gst);
     c->stats.launches_other += 2;
     if (lane_mode) {
-      launch_tlane_list(b, gmax, nseq, st);
+      launch_tlane_list(b, gmax, nseq, gst);
       c->stats.launches_other++;
     }
     const bool two = c->tree_two != 0;
@@ -1003,8 +1039,8 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
       // sums_external's first row and last column (k_tree_ext) trail the sweep by one band on
       // bulk_stream as well (the outside sweep is their only reader).
       auto boundary = [&](uint32_t x) -> int {  // "the sweep reached band x": bulk_stream may pass
-        HIPCHK(hipEventRecord(c->ev_a[x % ering], st));
-        HIPCHK(hipStreamWaitEvent(c->bulk_stream, c->ev_a[x % ering], 0));
+        HIPCHK(hipEventRecord(gev_a[x % ering], gst));
+        HIPCHK(hipStreamWaitEvent(gbulk, gev_a[x % ering], 0));
         return RNAMC_OK;
       };
       auto enqueue_mid = [&](bool outside, uint32_t x, uint32_t thr) -> int {
@@ -1012,8 +1048,8 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
 #ifdef RNAMC_DEBUG_KNOBS
         if (!(c->tree_debug & 32))  // (timing: the sweep without its mid-field kernels; results wrong)
 #endif
-        launch_tree_mid(b, outside, dlo, dhi, thr, gmax, active(dlo), c->tree_pol, c->bulk_stream);
-        HIPCHK(hipEventRecord(c->ev_b[x % ering], c->bulk_stream));
+        launch_tree_mid(b, outside, dlo, dhi, thr, gmax, active(dlo), c->tree_pol, gbulk);
+        HIPCHK(hipEventRecord(gev_b[x % ering], gbulk));
         c->stats.launches_other++;
         return RNAMC_OK;
       };
@@ -1023,7 +1059,7 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
 #ifdef RNAMC_DEBUG_KNOBS
         if (!(c->tree_debug & 64))
 #endif
-        launch_tree_ext(b, contra, dlo, dhi, gmax, active(dlo), c->bulk_stream);
+        launch_tree_ext(b, contra, dlo, dhi, gmax, active(dlo), gbulk);
         c->stats.launches_other++;
       };
       const bool sync_in = (lane_mode & 1u) != 0u && c->tree_mid_sync != 0;
@@ -1040,7 +1076,7 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
           // the mid-field of band x+1 can go
           if (lane_mode && cur_band != ~0u) {  // (their readers want the band row- / column-major)
             launch_tlane_spread(b, false, cur_band * band, std::min(gmax - 1, cur_band * band + band - 1), gmax,
-                                active(cur_band * band), st);
+                                active(cur_band * band), gst);
             c->stats.launches_other++;
           }
           rc = boundary(x);
@@ -1052,7 +1088,7 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
             // diagonal below x * band is final, so the launches keep the terms of the band alone)
             if (x >= 1) {
               launch_tree_mid(b, false, x * band, std::min(gmax - 1, x * band + band - 1), x * band, gmax,
-                              active(x * band), c->tree_pol, st);
+                              active(x * band), c->tree_pol, gst);
               c->stats.launches_other++;
             }
           } else {
@@ -1060,7 +1096,7 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
               rc = enqueue_mid(false, x + 1, x * band);
               if (rc) return rc;
             }
-            if (x >= 3) HIPCHK(hipStreamWaitEvent(st, c->ev_b[x % ering], 0));
+            if (x >= 3) HIPCHK(hipStreamWaitEvent(gst, gev_b[x % ering], 0));
           }
         }
         const uint32_t thr = sync_in ? x * band : (x >= 3 ? (x - 1) * band : 0u);
@@ -1069,15 +1105,15 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
           // at once — their slots read X4 up to their own diagonal minus four, i.e. up to d - 1)
           while (g_next <= d + 1 && g_next < gmax) {
             const uint32_t gc = std::min<uint32_t>(static_cast<uint32_t>(c->tree_gen_batch), gmax - g_next);
-            launch_tlane_gen(b, contra, false, g_next, gc, gmax, active(g_next), st);
+            launch_tlane_gen(b, contra, false, g_next, gc, gmax, active(g_next), gst);
             c->stats.launches_inside++;
             g_next += gc;
           }
           if (d == dmin_in) {  // (the first diagonal's closing-pair blocks)
-            launch_tlane_inside(b, contra, ~0u, d, gmax, active(d), 0u, st);
+            launch_tlane_inside(b, contra, ~0u, d, gmax, active(d), 0u, gst);
             c->stats.launches_inside++;
           }
-          launch_tlane_inside(b, contra, d, d + 1 < gmax ? d + 1 : ~0u, gmax, active(d), thr, st);
+          launch_tlane_inside(b, contra, d, d + 1 < gmax ? d + 1 : ~0u, gmax, active(d), thr, gst);
           c->stats.launches_inside++;
           d++;
           continue;
@@ -1086,7 +1122,7 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
         // the next launch's diagonals: their 2-loop blocks' far parts ride in this launch
         const uint32_t nd0 = d + (pair ? 2u : 1u);
         const uint32_t ndc = (!ahead || nd0 >= gmax) ? 0u : ((nd0 % 2u == 0u && nd0 + 1 < gmax) ? 2u : 1u);
-        launch_tree_inside(b, contra, d, gmax, active(d), c->tree_tpc, pair, thr, use_far, nd0, ndc, c->tree_pol, st);
+        launch_tree_inside(b, contra, d, gmax, active(d), c->tree_tpc, pair, thr, use_far, nd0, ndc, c->tree_pol, gst);
         use_far = ndc != 0u;
         c->stats.launches_inside++;
         d += pair ? 2 : 1;
@@ -1094,17 +1130,17 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
       if (cur_band != ~0u) {  // the last band's sums_external; the outside sweep reads them
         if (lane_mode) {
           launch_tlane_spread(b, false, cur_band * band, std::min(gmax - 1, cur_band * band + band - 1), gmax,
-                              active(cur_band * band), st);
+                              active(cur_band * band), gst);
           c->stats.launches_other++;
         }
         rc = boundary(cur_band + 1);
         if (rc) return rc;
         enqueue_ext(cur_band);
-        HIPCHK(hipEventRecord(c->ev_b[(cur_band + 1) % ering], c->bulk_stream));
-        HIPCHK(hipStreamWaitEvent(st, c->ev_b[(cur_band + 1) % ering], 0));
+        HIPCHK(hipEventRecord(gev_b[(cur_band + 1) % ering], gbulk));
+        HIPCHK(hipStreamWaitEvent(gst, gev_b[(cur_band + 1) % ering], 0));
       }
-      if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 1], st));
-      launch_tree_init(b, nseq, gmax, contra, 1, st);
+      if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 1], gst));
+      launch_tree_init(b, nseq, gmax, contra, 1, gst);
       c->stats.launches_other++;
       // Outside, from the top: band x takes the terms whose outside operand spans at least
       // thr = (x+2)*band (final once band x+2 is through) from k_tree_mid, enqueued when band x+1
@@ -1120,14 +1156,14 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
         if (x != cur_band) {
           if (lane_mode && cur_band != ~0u) {  // (the band above is through: W and R for the mid-field kernels)
             launch_tlane_spread(b, true, cur_band * band, std::min(gmax - 1, cur_band * band + band - 1), gmax,
-                                active(cur_band * band), st);
+                                active(cur_band * band), gst);
             c->stats.launches_other++;
           }
           cur_band = x;
           if (sync_out) {
             if ((x + 1) * band < gmax) {  // (operands of span >= (x+1)*band: everything above this band)
               launch_tree_mid(b, true, x * band, std::min(gmax - 1, x * band + band - 1), (x + 1) * band, gmax,
-                              active(x * band), c->tree_pol, st);
+                              active(x * band), c->tree_pol, gst);
               c->stats.launches_other++;
             }
           } else {
@@ -1137,7 +1173,7 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
               rc = enqueue_mid(true, x - 1, (x + 1) * band);
               if (rc) return rc;
             }
-            if ((x + 2) * band < gmax) HIPCHK(hipStreamWaitEvent(st, c->ev_b[x % ering], 0));
+            if ((x + 2) * band < gmax) HIPCHK(hipStreamWaitEvent(gst, gev_b[x % ering], 0));
           }
         }
         const uint32_t thr = sync_out ? ((x + 1) * band < gmax ? (x + 1) * band : 0u)
@@ -1148,17 +1184,17 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
           while (go_next >= static_cast<int64_t>(du) && go_next >= static_cast<int64_t>(dmin_out)) {
             const uint32_t gc = static_cast<uint32_t>(std::min<int64_t>(c->tree_gen_batch, go_next - static_cast<int64_t>(dmin_out) + 1));
             launch_tlane_gen(b, contra, true, static_cast<uint32_t>(go_next), gc, gmax,
-                             active(static_cast<uint32_t>(go_next) - (gc - 1u)), st);
+                             active(static_cast<uint32_t>(go_next) - (gc - 1u)), gst);
             c->stats.launches_outside++;
             go_next -= gc;
           }
           if (du == gmax - 1) {  // (the top diagonal's enclosing 2-loops: none exist, the slots are written)
-            launch_tlane_outside(b, contra, ~0u, du, gmax, active(du), 0u, st);
+            launch_tlane_outside(b, contra, ~0u, du, gmax, active(du), 0u, gst);
             c->stats.launches_outside++;
           }
           // (sequences that enter the sweep with the next launch need their 2-loop sums too)
           const uint32_t dn = du > dmin_out ? du - 1 : ~0u;
-          launch_tlane_outside(b, contra, du, dn, gmax, active(dn != ~0u ? dn : du), thr, st);
+          launch_tlane_outside(b, contra, du, dn, gmax, active(dn != ~0u ? dn : du), thr, gst);
           c->stats.launches_outside++;
           dd--;
           continue;
@@ -1175,47 +1211,51 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
         }
         // (sequences that enter the sweep with the next launch need their far parts too)
         launch_tree_outside(b, contra, lower, gmax, active(ndc ? nd0 : lower), c->tree_tpc, pair, thr, use_far,
-                            nd0, ndc, c->tree_pol, st);
+                            nd0, ndc, c->tree_pol, gst);
         use_far = ndc != 0u;
         dd -= pair ? 2 : 1;
         c->stats.launches_outside++;
       }
     } else {
     for (uint32_t d = dmin_in; d < gmax; d += two ? 2 : 1) {
-      launch_tree_inside(b, contra, d, gmax, active(d), c->tree_tpc, two, 0u, false, 0u, 0u, c->tree_pol, st);
+      launch_tree_inside(b, contra, d, gmax, active(d), c->tree_tpc, two, 0u, false, 0u, 0u, c->tree_pol, gst);
       c->stats.launches_inside++;
     }
-    if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 1], st));
-    launch_tree_init(b, nseq, gmax, contra, 1, st);
+    if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 1], gst));
+    launch_tree_init(b, nseq, gmax, contra, 1, gst);
     c->stats.launches_other++;
     if (two) {
       // pairs (d+1, d) from the top; the lowest diagonal alone when their number is odd
       int64_t d = static_cast<int64_t>(gmax) - 1;
       for (; d - 1 >= static_cast<int64_t>(dmin_out); d -= 2) {
         launch_tree_outside(b, contra, static_cast<uint32_t>(d - 1), gmax, active(static_cast<uint32_t>(d - 1)),
-                            c->tree_tpc, true, 0u, false, 0u, 0u, c->tree_pol, st);
+                            c->tree_tpc, true, 0u, false, 0u, 0u, c->tree_pol, gst);
         c->stats.launches_outside++;
       }
       if (d >= static_cast<int64_t>(dmin_out)) {
         launch_tree_outside(b, contra, static_cast<uint32_t>(d), gmax, active(static_cast<uint32_t>(d)),
-                            c->tree_tpc, false, 0u, false, 0u, 0u, c->tree_pol, st);
+                            c->tree_tpc, false, 0u, false, 0u, 0u, c->tree_pol, gst);
         c->stats.launches_outside++;
       }
     } else
     for (uint32_t d = gmax; d-- > dmin_out;) {
-      launch_tree_outside(b, contra, d, gmax, active(d), c->tree_tpc, false, 0u, false, 0u, 0u, c->tree_pol, st);
+      launch_tree_outside(b, contra, d, gmax, active(d), c->tree_tpc, false, 0u, false, 0u, 0u, c->tree_pol, gst);
       c->stats.launches_outside++;
     }
     }
-    if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 2], st));
-    launch_tree_finalize(b, nseq, gmax, st);
+    if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 2], gst));
+    launch_tree_finalize(b, nseq, gmax, gst);
     c->stats.launches_other++;
-    if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 3], st));
+    if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 3], gst));
     HIPCHK(hipGetLastError());
     if (hooks) {
       rc = hooks->after(g, gb, nseq);
       if (rc) return rc;
     }
+  }
+  if (dual) {  // (the caller's stream ends behind the second one)
+    HIPCHK(hipEventRecord(c->ev_dual, c->dual_stream));
+    HIPCHK(hipStreamWaitEvent(st, c->ev_dual, 0));
   }
   c->stats.tree_side_stream = static_cast<uint64_t>(c->side_probed ? c->side_verdict : 0);
   c->stats.n_groups = n_groups;
@@ -1393,6 +1433,10 @@ void rnamc_ctx_destroy(rnamc_ctx* c) {
     for (hipEvent_t e : c->ev_b) (void)hipEventDestroy(e);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->bulk_stream) (void)hipStreamDestroy(c->bulk_stream);
+    for (hipEvent_t e : c->ev_a2) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_b2) (void)hipEventDestroy(e);
+    if (c->ev_dual) (void)hipEventDestroy(c->ev_dual);
+
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->st_bases) (void)hipFree(c->st_bases);
     for (int k = 0; k < 2; k++) {
@@ -1447,6 +1491,8 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     c->tree_pol.mid_wgs = static_cast<uint32_t>(std::min<int64_t>(value, 1 << 20));
   } else if (k == "tree_ahead_waves" && value >= 0) {
     c->tree_pol.ahead_waves = static_cast<uint64_t>(value);
+  } else if (k == "tree_dual" && (value == 0 || value == 1)) {
+    c->tree_dual = value;
   } else if (k == "tree_gen_batch" && value >= 1 && value <= 3) {
     c->tree_gen_batch = value;
   } else if (k == "tree_lane_band" && value >= 32 && value <= 128 && value % 32 == 0) {

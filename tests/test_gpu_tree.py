@@ -42,7 +42,7 @@ def run(ctx, seqs, contra, short, mode, **knobs):
         ctx.set("summation_mode", 0)
         for k in knobs:
             ctx.set(k, {"tree_two": 1, "tree_tpc": 0, "tree_band": 64, "tree_ahead": 1, "tree_lane": 1,
-                        "tree_mid_sync": 1, "tree_mid_mx": 1, "tree_gen_batch": 3, "tree_lane_band": 32}[k])
+                        "tree_mid_sync": 1, "tree_mid_mx": 1, "tree_gen_batch": 3, "tree_lane_band": 32, "tree_dual": 1}[k])
 
 
 def deviation(a, b):
@@ -417,6 +417,58 @@ def test_tree_batch_form_many_sequences(ctx, params, contra):
         assert abs(float(z[k]) - xz) <= 2e-5 + 3e-6 * abs(xz)
     print(f"contra={contra}: 160 sequences, batch form against wave-per-cell launches: worst |dp| = {worst:.2f} x "
           f"(2e-5 + 2e-7 n); launches inside / outside {st['launches_inside']} / {st['launches_outside']}")
+
+
+@pytest.mark.parametrize("contra,short", VARIANTS)
+def test_tree_batch_form_two_groups_side_by_side(ctx, params, contra, short):
+    """Every other group of a batch-form call through the DEVICE-resident entry sweeps on a second stream with
+    its own half of the workspace (tree_dual; the host-buffer entry stages group by group and keeps one
+    stream): the same bits as one group after the other, whatever the number of groups (odd, even, a lone
+    last one) — and the same again with the call repeated (the halves are reused across groups)."""
+    import torch
+    lens = (600, 555, 430, 410, 390, 300, 260, 257, 200, 150, 99, 64, 7)
+    seqs = [O.splitmix_seq(n, 7 * n + 11) for n in lens]
+    ln = np.array(lens, dtype=np.uint64)
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    np.cumsum(ln, out=off[1:])
+    oo = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    np.cumsum(ln * (ln + np.uint64(1)) // np.uint64(2), out=oo[1:])
+    dev = torch.device("cuda:0")
+    d_b = torch.from_numpy(np.concatenate(seqs)).to(dev)
+
+    def call(dual):
+        d_o = torch.full((int(oo[-1]),), -7.0, dtype=torch.float32, device=dev)
+        d_z = torch.zeros(len(seqs), dtype=torch.float32, device=dev)
+        ctx.set("summation_mode", 1)
+        ctx.set("tree_lane", 2)
+        ctx.set("tree_dual", dual)
+        try:
+            ctx.bpp_batch_device(len(seqs), d_b.data_ptr(), off, contra, short, d_o.data_ptr(), oo, d_z.data_ptr(), 0)
+            torch.cuda.synchronize()
+            groups = ctx.stats()["n_groups"]
+        finally:
+            ctx.set("summation_mode", 0)
+            ctx.set("tree_lane", 1)
+            ctx.set("tree_dual", 1)
+        return d_o.cpu().numpy(), d_z.cpu().numpy(), groups
+
+    host, zhost = run(ctx, seqs, contra, short, 1, tree_lane=2)
+    for per_group in (2, 3, 5):
+        ctx.set("group_max_seqs", per_group)
+        try:
+            one, z_one, g1 = call(0)
+            two, z_two, g2 = call(1)
+            again, z_again, _ = call(1)
+        finally:
+            ctx.set("group_max_seqs", 8192)
+        assert g1 == g2 == -(-len(seqs) // per_group)
+        assert np.array_equal(one, two) and np.array_equal(one, again)
+        assert np.array_equal(z_one, z_two) and np.array_equal(z_one, z_again)
+        assert not np.any(one == -7.0)
+    # (and the host-buffer entry's result of the same batch in ONE group: other launch shapes, rounding)
+    for x, m in enumerate(host):
+        same, dp = deviation(one[int(oo[x]):int(oo[x + 1])], m.packed)
+        assert same and dp <= 2 * (2e-5 + 2e-7 * lens[x])
 
 
 def test_tree_edge_cases(ctx, params):
