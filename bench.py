@@ -1000,7 +1000,8 @@ def main():
             # pass, one timed pass, the golden members compared with their reference-order results.  Last
             # leg, and only when the time budget has room for it.
             est = pass_s / 2.5
-            if room_for(2.0 * est + 8.0):
+            # (a dozen seconds of margin on top: the leg must not be what pushes a run past the driver's limit)
+            if room_for(2.0 * est + 8.0 + 12.0):
                 ctx.set("summation_mode", 1)
                 try:
                     tt = []
