@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <cmath>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <limits>
@@ -1101,17 +1103,20 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
         }
         const uint32_t thr = sync_in ? x * band : (x >= 3 ? (x - 1) * band : 0u);
         if (lane_mode & 1u) {
-          // (the generic 2-loop sums of diagonal d + 1, wanted by this launch's second role: three diagonals
-          // at once — their slots read X4 up to their own diagonal minus four, i.e. up to d - 1)
+          if (d == dmin_in) {  // (the first diagonal's closing-pair blocks: in FRONT of the generic sums below —
+            // a batch of four enqueued ahead of it read X4 of this diagonal before it was written, which is
+            // what made four diagonals a launch differ under Turner tables, whose first diagonal is 4)
+            launch_tlane_inside(b, contra, ~0u, d, gmax, active(d), 0u, gst);
+            c->stats.launches_inside++;
+          }
+          // (the generic 2-loop sums of diagonal d + 1, wanted by this launch's second role: up to three
+          // diagonals at once — their slots read X4 up to their own diagonal minus four, i.e. up to d - 1;
+          // X4 is complete up to d)
           while (g_next <= d + 1 && g_next < gmax) {
             const uint32_t gc = std::min<uint32_t>(static_cast<uint32_t>(c->tree_gen_batch), gmax - g_next);
             launch_tlane_gen(b, contra, false, g_next, gc, gmax, active(g_next), gst);
             c->stats.launches_inside++;
             g_next += gc;
-          }
-          if (d == dmin_in) {  // (the first diagonal's closing-pair blocks)
-            launch_tlane_inside(b, contra, ~0u, d, gmax, active(d), 0u, gst);
-            c->stats.launches_inside++;
           }
           launch_tlane_inside(b, contra, d, d + 1 < gmax ? d + 1 : ~0u, gmax, active(d), thr, gst);
           c->stats.launches_inside++;
@@ -1140,6 +1145,25 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
         HIPCHK(hipStreamWaitEvent(gst, gev_b[(cur_band + 1) % ering], 0));
       }
       if (prof) HIPCHK(hipEventRecord(c->events[4 * g + 1], gst));
+#ifdef RNAMC_DEBUG_KNOBS
+      if (const char* dump = getenv("RNAMC_DUMP_MID")) {  // "<first slot>,<slots>,<path>": after the inside sweep
+        int s0 = 0, ns = 1;
+        char path[512] = {0};
+        if (sscanf(dump, "%d,%d,%500s", &s0, &ns, path) == 3) {
+          HIPCHK(hipDeviceSynchronize());
+          const TreeSeq& t0 = tseqs[gb];
+          std::vector<float> hbuf(static_cast<size_t>(ns) * t0.msz);
+          HIPCHK(hipMemcpy(hbuf.data(), b.workspace + t0.ws_off + static_cast<uint64_t>(s0) * t0.msz,
+                           hbuf.size() * sizeof(float), hipMemcpyDeviceToHost));
+          if (FILE* fh = fopen(path, "wb")) {
+            const uint64_t hdr[3] = {t0.n, t0.ld, t0.msz};
+            fwrite(hdr, sizeof(hdr), 1, fh);
+            fwrite(hbuf.data(), sizeof(float), hbuf.size(), fh);
+            fclose(fh);
+          }
+        }
+      }
+#endif
       launch_tree_init(b, nseq, gmax, contra, 1, gst);
       c->stats.launches_other++;
       // Outside, from the top: band x takes the terms whose outside operand spans at least
@@ -1257,6 +1281,25 @@ int run_batch_tree(rnamc_ctx* c, uint32_t n_seqs, const uint8_t* d_bases, const 
     HIPCHK(hipEventRecord(c->ev_dual, c->dual_stream));
     HIPCHK(hipStreamWaitEvent(st, c->ev_dual, 0));
   }
+#ifdef RNAMC_DEBUG_KNOBS
+  if (const char* dump = getenv("RNAMC_DUMP_SLOT")) {  // "<first slot>,<slots>,<path>": the first sequence's matrices, raw
+    int s0 = 0, ns = 1;
+    char path[512] = {0};
+    if (sscanf(dump, "%d,%d,%500s", &s0, &ns, path) == 3 && !tseqs.empty()) {
+      HIPCHK(hipDeviceSynchronize());
+      const TreeSeq& t0 = tseqs[0];
+      std::vector<float> hbuf(static_cast<size_t>(ns) * t0.msz);
+      HIPCHK(hipMemcpy(hbuf.data(), c->d_ws + t0.ws_off + static_cast<uint64_t>(s0) * t0.msz, hbuf.size() * sizeof(float),
+                       hipMemcpyDeviceToHost));
+      if (FILE* fh = fopen(path, "wb")) {
+        const uint64_t hdr[3] = {t0.n, t0.ld, t0.msz};
+        fwrite(hdr, sizeof(hdr), 1, fh);
+        fwrite(hbuf.data(), sizeof(float), hbuf.size(), fh);
+        fclose(fh);
+      }
+    }
+  }
+#endif
   c->stats.tree_side_stream = static_cast<uint64_t>(c->side_probed ? c->side_verdict : 0);
   c->stats.n_groups = n_groups;
   c->stats.workspace_bytes = c->ws_floats * sizeof(float);
@@ -1493,7 +1536,11 @@ int rnamc_ctx_set(rnamc_ctx* c, const char* name, int64_t value) {
     c->tree_pol.ahead_waves = static_cast<uint64_t>(value);
   } else if (k == "tree_dual" && (value == 0 || value == 1)) {
     c->tree_dual = value;
+#ifdef RNAMC_GEN_DIAGS
+  } else if (k == "tree_gen_batch" && value >= 1 && value <= RNAMC_GEN_DIAGS) {  // (experiments: see k_tlane_gen)
+#else
   } else if (k == "tree_gen_batch" && value >= 1 && value <= 3) {
+#endif
     c->tree_gen_batch = value;
   } else if (k == "tree_lane_band" && value >= 32 && value <= 128 && value % 32 == 0) {
     c->tree_lane_band = value;

@@ -575,13 +575,18 @@ __global__ void __launch_bounds__(64 * kLaneParts) k_tlane_outside(TreeBatch b, 
 // is ~70 MB a launch — i.e. each ~29 times over the sweep.  Here the workgroup's twelve waves are three
 // diagonals x four parts over the same stretch of the lists (the same rows, give or take the lists'
 // drift), in step through the slots ordered by a + b: the lines meet in the CU's L1.  Possible because
-// the generic slots never touch the last three diagonals.  (Four diagonals — up to the newest diagonal
-// the slots may read — gave results that differed under Turner tables, deterministically, and agreed
-// again when the sums were formed a second time just in time; three agree to the bit with one diagonal a
-// launch on every length tried, scripts/gen_batch_check.py: the batch stays at three, the cause is not understood.)
+// the generic slots never touch the last three diagonals: after a finished diagonal d the sums of d + 1 ..
+// d + 4 could go at once.  Three are taken (twelve waves): four — sixteen waves, 1 024 threads — were
+// slower (685 against 659 ms on the 1 000-sequence slice).  (The four-diagonal form first gave differing
+// results under Turner tables: the sweep's very first batch was enqueued in FRONT of the first diagonal's
+// closing-pair blocks and read their X4 before it was written — found with a mid-sweep dump of T_GEN_D,
+// scripts/gen4_probe2.py, and fixed in the host schedule; three diagonals never reached that diagonal.)
 // The sum of a cell goes to T_GEN_D as a {max, sum} pair; the just-in-time rest of the block — hairpin,
 // multibranch, explicit small loops — stays with the sweep's launches.
-constexpr uint32_t kGenDiags = 3u;
+#ifndef RNAMC_GEN_DIAGS
+#define RNAMC_GEN_DIAGS 3
+#endif
+constexpr uint32_t kGenDiags = RNAMC_GEN_DIAGS;
 template <bool CONTRA, bool OUTSIDE>
 __global__ void __launch_bounds__(64 * kLaneParts * kGenDiags) k_tlane_gen(TreeBatch b, uint32_t g0, uint32_t gcount) {
   __shared__ float2 red[kGenDiags][kLaneParts][64];
